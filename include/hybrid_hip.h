@@ -1,0 +1,201 @@
+/*
+ * hybrid_hip.h -- C ABI of libhybrid_hip.so, the MI355X (gfx950) implementation of
+ * the CNN + temporal-transformer hot path (forward and backward).
+ *
+ * The reference (spygaurad/Transformer-CNN-Hybrid-Network-for-Video-Processing) has NO
+ * native / FFI interface: every op on its hot path is a stock torch.nn call made from
+ * nn.Module.forward.  Each entry point below therefore replaces
+ * the torch dispatch the cited reference line makes; INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the Python side.
+ *
+ * Contract:
+ *   - extern "C", plain pointers and sizes only; no torch types.
+ *   - the CALLER owns every buffer (inputs, outputs, saved activations, workspace);
+ *     the library never allocates or frees device memory and keeps no global state.
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately; no internal synchronisation; re-entrant.
+ *   - return value: 0 = success; negative = argument check failed (HYB_E_*);
+ *     positive = hipError_t from a launch.  Nothing throws across the ABI.
+ *   - `dtype` selects the storage/MFMA-operand type T of activations:
+ *       HYB_F32  : fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32; the parity gate)
+ *       HYB_BF16 : bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate/statistics
+ *     Parameters (weights, biases, BN/LN affine, running stats) and parameter
+ *     gradients are always fp32.
+ *   - internal activation layout is NHWC with the channel count padded to a multiple
+ *     of 32 ("Cp"); padded channels hold zeros.  The user-facing clip tensor stays
+ *     NCHW fp32 ([B*T, C, H, W]) and is read directly by the first conv stage.
+ */
+#ifndef HYBRID_HIP_H_
+#define HYBRID_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYB_F32 0
+#define HYB_BF16 1
+
+#define HYB_E_ARG (-1)      /* bad argument (null pointer, unsupported size) */
+#define HYB_E_WORKSPACE (-2) /* workspace too small */
+
+/* ---- misc ------------------------------------------------------------------------- */
+int hyb_abi_version(void);
+/* bytes per element of dtype (4 or 2); HYB_E_ARG otherwise */
+int hyb_dtype_size(int dtype);
+/* round a channel count up to the internal padded count */
+int hyb_pad_channels(int c);
+
+/* layout conversion helpers (used by tests and by in_channels > 3):
+ * NCHW fp32 [N,C,H,W] <-> NHWC T [N,H,W,Cp] (padded channels written as zero). */
+int hyb_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, void* stream);
+int hyb_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, void* stream);
+/* T <-> fp32 elementwise cast of n elements */
+int hyb_cast_to_f32(int dtype, const void* src, float* dst, long long n, void* stream);
+int hyb_cast_from_f32(int dtype, const float* src, void* dst, long long n, void* stream);
+
+/* ---- conv stage pieces: replace nn.Conv2d / BatchNorm2d / ReLU / MaxPool2d ----------
+ * reference: UNet.py:58 (Conv2d 3x3 pad 1 bias=False), UNet.py:59 (BatchNorm2d),
+ * UNet.py:60 (ReLU), UNet.py:13 (MaxPool2d(2,2)).                                      */
+
+/* number of T elements of a packed weight: first ? Cop*32 : Cop*9*Cip */
+long long hyb_conv_packed_elems(int first, int Cip, int Cop);
+/* w fp32 [Co,Ci,3,3] -> packed T.  mode 0: forward   wp[co][tap][ci]   (Cop x 9 x Cip)
+ *                                  mode 1: dgrad     wp[ci][8-tap][co] (Cip x 9 x Cop)
+ *                                  mode 2: first layer wp[co][k=tap*Ci+ci] (Cop x 32), Ci<=3 */
+int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, int Ci, int Cop, int Cip, void* stream);
+
+/* y[N,H,W,Cop] = conv3x3(x, wp), stride 1, zero pad 1.
+ * first=1: x is NCHW fp32 [N,Ci,H,W] with Ci<=3 (Cip ignored), wp packed with mode 2.
+ * first=0: x is NHWC T [N,H,W,Cip], wp packed with mode 0 (or mode 1 for dgrad, with
+ *          Cip/Cop exchanged by the caller).
+ * stats: NULL, or fp32 [2][Cop] (sum, sum of squares per output channel over N*H*W),
+ *        ACCUMULATED into (caller zeroes it). */
+int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats,
+                    int N, int H, int W, int Ci, int Cip, int Cop, void* stream);
+
+/* BatchNorm2d statistics -> per-channel scale/shift (UNet.py:59; torch semantics:
+ * training: batch mean, biased var for normalisation, running stats updated with
+ * momentum and UNBIASED var, num_batches_tracked += 1; eval: running stats).
+ * scale_shift fp32 [2][Cop]; mean_invstd fp32 [2][Cop] (saved for backward). */
+int hyb_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, int training, float momentum,
+                    float eps, long long count, int Co, int Cop, float* scale_shift, float* mean_invstd,
+                    void* stream);
+
+/* pooled[N,H/2,W/2,Cop] = maxpool2x2(relu(y*scale+shift)) (floor; H,W >= 2) */
+int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, void* pooled,
+                         int N, int H, int W, int Cop, void* stream);
+
+/* backward of pool+relu+BN, two passes:
+ *  reduce: sums[2][Cop] += (sum dy, sum dy*xhat) with dy routed through pool argmax and relu
+ *  dx    : dyraw[N,H,W,Cop] = gamma*invstd*(dy - sum_dy/count - xhat*sum_dyxhat/count) (training)
+ *                             gamma*invstd*dy                                        (eval)
+ *          and writes dgamma[Co] = sum dy*xhat, dbeta[Co] = sum dy. */
+int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* scale_shift,
+                                const float* mean_invstd, float* sums, int N, int H, int W, int Cop, void* stream);
+int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const float* scale_shift,
+                            const float* mean_invstd, const float* gamma, const float* sums, int training,
+                            long long count, void* dyraw, float* dgamma, float* dbeta,
+                            int N, int H, int W, int Co, int Cop, void* stream);
+
+/* weight gradient of the conv: dw fp32 [Co,Ci,3,3] = sum_{n,h,w} dy (x) patch(x).
+ * x as in hyb_conv3x3_fwd (first selects NCHW fp32 input).  workspace: fp32 slabs. */
+size_t hyb_conv3x3_wgrad_workspace(int first, int N, int H, int W, int Cip, int Cop);
+int hyb_conv3x3_wgrad(int dtype, int first, const void* x, const void* dy, float* dw,
+                      int N, int H, int W, int Ci, int Cip, int Co, int Cop,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- whole conv stage (Conv3x3 -> BN -> ReLU -> MaxPool), UNet.py:58-60 + :13 -------- */
+size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop);
+int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, int training, float momentum, float eps,
+                      int N, int H, int W, int Ci, int Cip, int Co, int Cop,
+                      void* y_raw /* [N,H,W,Cop] T, saved */, void* pooled /* [N,H/2,W/2,Cop] T */,
+                      float* scale_shift /* [2][Cop] saved */, float* mean_invstd /* [2][Cop] saved */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop);
+int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw,
+                      const float* weight, const float* gamma, const float* scale_shift,
+                      const float* mean_invstd, int training,
+                      int N, int H, int W, int Ci, int Cip, int Co, int Cop,
+                      void* dx /* [N,H,W,Cip] T, NULL when first */, float* dweight, float* dgamma, float* dbeta,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- frame token: global average pool over H*W (the composite's own glue) ----------- */
+int hyb_gap_fwd(int dtype, const void* x /* [N,HW,Cp] */, void* feat /* [N,Cp] */, int N, int HW, int Cp, void* stream);
+int hyb_gap_bwd(int dtype, const void* dfeat /* [N,Cp] */, void* dx /* [N,HW,Cp] */, int N, int HW, int Cp, void* stream);
+
+/* ---- nn.Linear: y = x W^T + b (TransformerEncoder.pyc src L12-15, L69, L87, L107) ----
+ * x [M,K] T with row stride ldx (elements), W fp32 [N,K], b fp32 [N] or NULL, y [M,N] T.
+ * relu=1 applies ReLU in the epilogue (src L70 / the FFN's nn.ReLU). */
+int hyb_linear_fwd(int dtype, const void* x, int ldx, const float* W, const float* b, void* y,
+                   int M, int N, int K, int relu, void* stream);
+/* backward: if relu, dy is first masked by (y > 0) (y = saved forward output).
+ * dx [M,K] T (ldx stride; accumulate_dx=1 adds into it), dW fp32 [N,K], db fp32 [N] (both overwritten).
+ * dx, dW or db may be NULL to skip.  workspace: M*N T elements (masked dy) when relu. */
+int hyb_linear_bwd(int dtype, const void* x, int ldx, const float* W, const void* y, const void* dy,
+                   void* dx, int accumulate_dx, float* dW, float* db, int M, int N, int K, int relu,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- attention core: TransformerEncoder.pyc src L49-62 with the head split of L22-45 --
+ * q,k,v,out: [B,S,D] T (token-major; head h = feature slice [h*D/H,(h+1)*D/H), batch index
+ * b*H+h).  scores = q k^T / sqrt(D) (D = d_model, quirk Q1); mask: NULL or fp32 [B,S,S],
+ * row b*H+h uses mask[(b*H+h) % B] (quirk Q4: mask.repeat(H,1,1)); masked_fill(mask==0,-1e9);
+ * softmax; dropout(p_drop) on the weights (src L58, counter-based RNG keyed by seed);
+ * out = weights v.  probs: fp32 [B*H,S,S] softmax output BEFORE dropout (saved for backward).
+ * Limits: S <= 64, D/H in {16,32,64,96,128} (multiple of 16, <= 128). */
+int hyb_attention_fwd(int dtype, const void* q, const void* k, const void* v, const float* mask,
+                      void* out, float* probs, int B, int S, int D, int H, float p_drop,
+                      unsigned long long seed, void* stream);
+int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* probs,
+                      const void* dout, void* dq, void* dk, void* dv, int B, int S, int D, int H,
+                      float p_drop, unsigned long long seed, void* stream);
+
+/* ---- LayerNorm + residual (+ scale, + dropout): src L116-117 / L120-123 ---------------
+ * y = dropout_p( (LayerNorm(x)*gamma + beta + skip) * out_scale ).  stats fp32 [2][M]. */
+int hyb_ln_residual_fwd(int dtype, const void* x, const void* skip, const float* gamma, const float* beta,
+                        void* y, float* stats, int M, int D, float eps, float out_scale, float p_drop,
+                        unsigned long long seed, void* stream);
+/* dx, dskip [M,D] T; dgamma/dbeta fp32 [D] are ACCUMULATED into (one LayerNorm instance is
+ * applied twice per layer, quirk Q3).  accumulate_dskip=1 adds into dskip. */
+int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* stats,
+                        void* dx, void* dskip, int accumulate_dskip, float* dgamma, float* dbeta,
+                        int M, int D, float out_scale, float p_drop, unsigned long long seed, void* stream);
+
+/* ---- whole TransformerEncoder.forward(input, mask): src L110-126 ----------------------
+ * params: host array of L*14 device pointers (fp32), per layer in this order:
+ *   Wq,bq,Wk,bk,Wv,bv,Wo,bo (attention_layers.i.{query,key,value,output}_layer.{weight,bias}),
+ *   W1,b1,W2,b2 (feedforward_layers.i.{0,2}.{weight,bias}), ln_w, ln_b (layer_norm.i).
+ * grads: same order, fp32, overwritten.  saved: caller buffer of hyb_encoder_saved_bytes.
+ * attn_p = attention-weight dropout (0.1 in train mode, 0 in eval: quirk Q5);
+ * layer_p = per-layer dropout (always active: quirk Q6). */
+size_t hyb_encoder_saved_bytes(int dtype, int B, int S, int D, int Hid, int L, int H);
+size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, int Hid, int L, int H);
+int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out,
+                    void* saved, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
+                    unsigned long long seed, void* stream);
+int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params,
+                    float* const* grads, const void* saved, void* dx, int B, int S, int D, int Hid, int L,
+                    int H, float attn_p, float layer_p, unsigned long long seed,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- head: mean over T then Linear(d, classes) (composite's own) ---------------------- */
+int hyb_head_fwd(int dtype, const void* x /* [B,S,D] T */, const float* W /* [C,D] */, const float* b,
+                 float* logits /* [B,C] fp32 */, int B, int S, int D, int C, void* stream);
+int hyb_head_bwd(int dtype, const void* x, const float* W, const float* dlogits /* [B,C] */,
+                 void* dx /* [B,S,D] T */, float* dW, float* db, int B, int S, int D, int C, void* stream);
+
+/* ---- loss: mean cross-entropy over the batch (composite's own) ------------------------ */
+int hyb_cross_entropy_fwd(const float* logits, const long long* target, float* loss /* [1] */,
+                          int B, int C, void* stream);
+int hyb_cross_entropy_bwd(const float* logits, const long long* target, const float* dloss /* [1] */,
+                          float* dlogits, int B, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYBRID_HIP_H_ */

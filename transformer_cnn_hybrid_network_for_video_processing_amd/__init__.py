@@ -1,0 +1,5 @@
+"""MI355X-native (gfx950) CNN backbone + temporal Transformer encoder hot path."""
+from .modules import (ConvBNReLUPool, HybridCrossEntropyLoss, MultiheadAttention, TransformerCNNHybrid,  # noqa: F401
+                      TransformerEncoder)
+
+__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss"]

@@ -1,0 +1,87 @@
+"""ctypes binding of libhybrid_hip.so.  Prototypes are parsed from include/hybrid_hip.h so the
+Python side cannot drift from the C ABI.  There is NO fallback: if the shared object is missing or
+a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+HEADER = os.path.join(ROOT, "include", "hybrid_hip.h")
+LIB_PATH = os.path.join(PKG, "libhybrid_hip.so")
+
+HYB_F32, HYB_BF16 = 0, 1
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong,
+    "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [argtype_str, ...])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|long long)\s+(hyb_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append("ptr")
+                else:
+                    a = re.sub(r"\bconst\b", "", a).strip()
+                    a = re.sub(r"\s+\w+$", "", a).strip()      # drop the parameter name
+                    argtypes.append(a)
+        protos[name] = (ret, argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def _load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `python -m transformer_cnn_hybrid_network_for_video_processing_amd.build`). "
+                "There is no CPU/eager fallback for this path.")
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(dll, name)            # AttributeError if the .so does not export a declared symbol
+            fn.restype = _CTYPES[ret]
+            fn.argtypes = [ctypes.c_void_p if a == "ptr" else _CTYPES[a] for a in args]
+        self._dll = dll
+        return dll
+
+    def raw(self, name):
+        return getattr(self._load(), name)
+
+    def call(self, name, *args):
+        """Call an int-returning entry point; raise on a non-zero status."""
+        rc = getattr(self._load(), name)(*args)
+        if rc != 0:
+            kind = "argument check" if rc == -1 else "workspace too small" if rc == -2 else f"hipError_t {rc}"
+            raise RuntimeError(f"{name} failed: {kind} (status {rc})")
+
+    def query(self, name, *args):
+        """Call a size/count-returning entry point."""
+        return getattr(self._load(), name)(*args)
+
+
+lib = _Lib()
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers for `const float* const*` parameters."""
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)

@@ -1,0 +1,62 @@
+"""Build libhybrid_hip.so (gfx950) in-tree with hipcc.  No torch headers are involved:
+the library is a plain C-ABI shared object (include/hybrid_hip.h)."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libhybrid_hip.so")
+SOURCES = ["conv_fwd.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "hybrid_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, jobs=4):
+    """Compile every HIP source for gfx950 and link the shared object next to this file."""
+    if not force and not needs_build():
+        return LIB
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+             "-Wno-unused-result"]
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        if len(procs) >= jobs:
+            _drain(procs)
+    _drain(procs)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    return LIB
+
+
+def _drain(procs):
+    while procs:
+        src, p = procs.pop(0)
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

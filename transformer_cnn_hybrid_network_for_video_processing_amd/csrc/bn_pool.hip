@@ -1,0 +1,411 @@
+// BatchNorm2d (UNet.py:59) + ReLU (UNet.py:60) + MaxPool2d(2,2) (UNet.py:13) on NHWC activations,
+// forward and backward, plus the global-average-pool frame token and layout/cast helpers.
+// All of these are HBM-bound streaming kernels: 8 channels (16 B of bf16) per lane, channel-fastest.
+#include "hyb_common.h"
+
+namespace {
+
+// ---- BN statistics -> scale/shift -------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                   int training, float momentum, float eps, long long count, int Co, int Cop,
+                                   float* __restrict__ scale_shift, float* __restrict__ mean_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training && nbt) *nbt += 1;
+    if (c >= Cop) return;
+    float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
+    if (c < Co) {
+        g = gamma[c];
+        b = beta[c];
+        if (training) {
+            const float inv_n = 1.0f / (float)count;
+            mean = stats[c] * inv_n;
+            float var = stats[Cop + c] * inv_n - mean * mean;      // biased variance (normalisation)
+            var = fmaxf(var, 0.f);
+            invstd = rsqrtf(var + eps);
+            const float unbiased = count > 1 ? var * ((float)count / (float)(count - 1)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        } else {
+            mean = running_mean[c];
+            invstd = rsqrtf(running_var[c] + eps);
+        }
+    }
+    const float scale = g * invstd;
+    scale_shift[c] = scale;
+    scale_shift[Cop + c] = b - mean * scale;
+    mean_invstd[c] = mean;
+    mean_invstd[Cop + c] = invstd;
+}
+
+// first maximum of the four transformed values in torch's window scan order (0,0),(0,1),(1,0),(1,1)
+__device__ __forceinline__ int argmax4(float v0, float v1, float v2, float v3, float& vmax) {
+    int a = 0;
+    vmax = v0;
+    if (v1 > vmax) { vmax = v1; a = 1; }
+    if (v2 > vmax) { vmax = v2; a = 2; }
+    if (v3 > vmax) { vmax = v3; a = 3; }
+    return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ out,
+                                                               int H, int W, int Cop, long long total) {
+    const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % OCT);
+        const long long pix = i / OCT;
+        const int wo = (int)(pix % Wo);
+        const long long t2 = pix / Wo;
+        const int ho = (int)(t2 % Ho);
+        const long long n = t2 / Ho;
+        const T* src = y + (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
+        Vec8<T> a, b, c, d;
+        a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = ss[oc * 8 + j], sh = ss[Cop + oc * 8 + j];
+            float m = fmaxf(fmaxf(a.get(j) * sc + sh, b.get(j) * sc + sh), fmaxf(c.get(j) * sc + sh, d.get(j) * sc + sh));
+            o.set(j, fmaxf(m, 0.f));
+        }
+        o.store(out + pix * Cop + oc * 8);
+    }
+}
+
+// pass 1 of the backward: per-channel sum(dy) and sum(dy * xhat), dy routed through argmax and relu.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* __restrict__ dp, const T* __restrict__ y,
+                                                                      const float* __restrict__ ss, const float* __restrict__ mi,
+                                                                      float* __restrict__ sums, int H, int W, int Cop, long long total) {
+    extern __shared__ float red[];                 // [2][Cop]
+    const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
+    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    // the grid stride is a multiple of OCT, so a thread always owns the same 8 channels
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int oc = (int)(i0 % OCT);
+    float sc[8], sh[8], mean[8], inv[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = ss[oc * 8 + j]; sh[j] = ss[Cop + oc * 8 + j];
+        mean[j] = mi[oc * 8 + j]; inv[j] = mi[Cop + oc * 8 + j];
+        a1[j] = 0.f; a2[j] = 0.f;
+    }
+    for (long long i = i0; i < total; i += stride) {
+        const long long pix = i / OCT;
+        const int wo = (int)(pix % Wo);
+        const long long t2 = pix / Wo;
+        const int ho = (int)(t2 % Ho);
+        const long long n = t2 / Ho;
+        const T* src = y + (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
+        Vec8<T> a, b, c, d, g;
+        a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
+        g.load(dp + pix * Cop + oc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
+            float vmax;
+            const int am = argmax4(y0 * sc[j] + sh[j], y1 * sc[j] + sh[j], y2 * sc[j] + sh[j], y3 * sc[j] + sh[j], vmax);
+            const float ysel = am == 0 ? y0 : am == 1 ? y1 : am == 2 ? y2 : y3;
+            const float dy = vmax > 0.f ? g.get(j) : 0.f;
+            a1[j] += dy;
+            a2[j] += dy * (ysel - mean[j]) * inv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        atomicAdd(&red[oc * 8 + j], a1[j]);
+        atomicAdd(&red[Cop + oc * 8 + j], a2[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) atomicAdd(&sums[i], red[i]);
+}
+
+// pass 2: dense gradient w.r.t. the raw conv output.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_dx_kernel(const T* __restrict__ dp, const T* __restrict__ y,
+                                                                  const float* __restrict__ ss, const float* __restrict__ mi,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                  int training, float inv_count, T* __restrict__ dyraw,
+                                                                  int H, int W, int Co, int Cop, long long total) {
+    const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
+    const bool oddW = (W & 1) != 0, oddH = (H & 1) != 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % OCT);
+        const long long pix = i / OCT;
+        const int wo = (int)(pix % Wo);
+        const long long t2 = pix / Wo;
+        const int ho = (int)(t2 % Ho);
+        const long long n = t2 / Ho;
+        const long long base = (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
+        Vec8<T> a, b, c, d, g;
+        a.load(y + base); b.load(y + base + Cop); c.load(y + base + (long long)W * Cop); d.load(y + base + (long long)W * Cop + Cop);
+        g.load(dp + pix * Cop + oc * 8);
+        Vec8<T> o0, o1, o2, o3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = oc * 8 + j;
+            const float sc = ss[ch], sh = ss[Cop + ch], mean = mi[ch], inv = mi[Cop + ch];
+            const float gm = ch < Co ? gamma[ch] : 0.f;
+            const float k = gm * inv;
+            const float m1 = training ? sums[ch] * inv_count : 0.f;
+            const float m2 = training ? sums[Cop + ch] * inv_count : 0.f;
+            const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
+            float vmax;
+            const int am = argmax4(y0 * sc + sh, y1 * sc + sh, y2 * sc + sh, y3 * sc + sh, vmax);
+            const float dy = vmax > 0.f ? g.get(j) : 0.f;
+            o0.set(j, k * ((am == 0 ? dy : 0.f) - m1 - (y0 - mean) * inv * m2));
+            o1.set(j, k * ((am == 1 ? dy : 0.f) - m1 - (y1 - mean) * inv * m2));
+            o2.set(j, k * ((am == 2 ? dy : 0.f) - m1 - (y2 - mean) * inv * m2));
+            o3.set(j, k * ((am == 3 ? dy : 0.f) - m1 - (y3 - mean) * inv * m2));
+        }
+        o0.store(dyraw + base); o1.store(dyraw + base + Cop);
+        o2.store(dyraw + base + (long long)W * Cop); o3.store(dyraw + base + (long long)W * Cop + Cop);
+        // odd H/W: the last row/column is outside every pooling window (floor) but still carries the
+        // mean / xhat terms of the batch-norm gradient
+        if (oddW && wo == Wo - 1) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const long long bb = base + 2 * Cop + (long long)rr * W * Cop;
+                Vec8<T> e, oe;
+                e.load(y + bb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = oc * 8 + j;
+                    const float k = (ch < Co ? gamma[ch] : 0.f) * mi[Cop + ch];
+                    const float m1 = training ? sums[ch] * inv_count : 0.f, m2 = training ? sums[Cop + ch] * inv_count : 0.f;
+                    oe.set(j, k * (-m1 - (e.get(j) - mi[ch]) * mi[Cop + ch] * m2));
+                }
+                oe.store(dyraw + bb);
+            }
+        }
+        if (oddH && ho == Ho - 1) {
+            const int ncol = (oddW && wo == Wo - 1) ? 3 : 2;
+            for (int cc = 0; cc < ncol; ++cc) {
+                const long long bb = base + 2ll * W * Cop + (long long)cc * Cop;
+                Vec8<T> e, oe;
+                e.load(y + bb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = oc * 8 + j;
+                    const float k = (ch < Co ? gamma[ch] : 0.f) * mi[Cop + ch];
+                    const float m1 = training ? sums[ch] * inv_count : 0.f, m2 = training ? sums[Cop + ch] * inv_count : 0.f;
+                    oe.set(j, k * (-m1 - (e.get(j) - mi[ch]) * mi[Cop + ch] * m2));
+                }
+                oe.store(dyraw + bb);
+            }
+        }
+    }
+}
+
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Co) return;
+    if (dbeta) dbeta[c] = sums[c];
+    if (dgamma) dgamma[c] = sums[Cop + c];
+}
+
+// ---- global average pool ------------------------------------------------------------------
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ feat, int HW, int Cp, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int OCT = Cp >> 3;
+    const int oc = (int)(i % OCT);
+    const long long n = i / OCT;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const T* src = x + n * HW * Cp + oc * 8;
+    for (int p = 0; p < HW; ++p) {
+        Vec8<T> v;
+        v.load(src + (long long)p * Cp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v.get(j);
+    }
+    Vec8<T> o;
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.set(j, acc[j] * inv);
+    o.store(feat + n * Cp + oc * 8);
+}
+template <typename T>
+__global__ void gap_bwd_kernel(const T* __restrict__ dfeat, T* __restrict__ dx, int HW, int Cp, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int OCT = Cp >> 3;
+    const int oc = (int)(i % OCT);
+    const long long np = i / OCT;       // n*HW + p
+    const long long n = np / HW;
+    Vec8<T> v, o;
+    v.load(dfeat + n * Cp + oc * 8);
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.set(j, v.get(j) * inv);
+    o.store(dx + np * Cp + oc * 8);
+}
+
+// ---- layout / cast helpers ------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int H, int W, int Cp, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % Cp);
+    const long long pix = i / Cp;
+    const long long hw = (long long)H * W;
+    const long long n = pix / hw, p = pix % hw;
+    dst[i] = from_f32<T>(c < C ? src[(n * C + c) * hw + p] : 0.f);
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int Cp, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long hw = (long long)H * W;
+    const long long p = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long long n = i / (hw * C);
+    dst[i] = to_f32<T>(src[(n * hw + p) * Cp + c]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ s, float* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = to_f32<T>(s[i]);
+}
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = from_f32<T>(s[i]);
+}
+
+inline int stream_grid(long long total, int cap = 4096) {
+    long long b = (total + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define HYB_DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    do { if ((dtype) == HYB_F32) { CALL_F32; } else if ((dtype) == HYB_BF16) { CALL_BF16; } else return HYB_E_ARG; } while (0)
+
+extern "C" int hyb_abi_version(void) { return 1; }
+extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
+extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }
+
+extern "C" int hyb_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               long long* nbt, int training, float momentum, float eps, long long count, int Co, int Cop,
+                               float* scale_shift, float* mean_invstd, void* stream) {
+    HYB_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && mean_invstd && Co > 0 && Cop >= Co && count > 0);
+    HYB_CHECK_ARG(!training || stats);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(hyb_cdiv(Cop, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, running_mean,
+                       running_var, nbt, training, momentum, eps, count, Co, Cop, scale_shift, mean_invstd);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* ss, void* pooled, int N, int H, int W, int Cop, void* stream) {
+    HYB_CHECK_ARG(y && ss && pooled && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0);
+    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, st, (const float*)y, ss, (float*)pooled, H, W, Cop, total),
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16>, dim3(stream_grid(total)), dim3(256), 0, st, (const bf16*)y, ss, (bf16*)pooled, H, W, Cop, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* ss, const float* mi, float* sums,
+                                           int N, int H, int W, int Cop, void* stream) {
+    HYB_CHECK_ARG(dpooled && y && ss && mi && sums && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0);
+    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
+    const int oct = Cop / 8;
+    // grid*256 must be a multiple of oct so each thread keeps one channel octet: oct = 4*m, 256 = 4*64 => grid multiple of m/gcd(m,64)
+    int m = oct / 4, g = 64;
+    { int a = m, b = g; while (b) { int t = a % b; a = b; b = t; } m /= a; }
+    int grid = stream_grid(total, 2048);
+    grid = (grid + m - 1) / m * m;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 2 * (size_t)Cop * sizeof(float);
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, sums, H, W, Cop, total),
+        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, sums, H, W, Cop, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const float* ss, const float* mi, const float* gamma,
+                                       const float* sums, int training, long long count, void* dyraw, float* dgamma, float* dbeta,
+                                       int N, int H, int W, int Co, int Cop, void* stream) {
+    HYB_CHECK_ARG(dpooled && y && ss && mi && gamma && sums && dyraw && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Co <= Cop && count > 0);
+    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
+    const float inv_count = 1.0f / (float)count;
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, st, (const float*)dpooled, (const float*)y, ss, mi, gamma, sums, training, inv_count, (float*)dyraw, H, W, Co, Cop, total),
+        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<bf16>, dim3(stream_grid(total)), dim3(256), 0, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, gamma, sums, training, inv_count, (bf16*)dyraw, H, W, Co, Cop, total));
+    HYB_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hyb_cdiv(Co, 256)), dim3(256), 0, st, sums, dgamma, dbeta, Co, Cop);
+        HYB_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int hyb_gap_fwd(int dtype, const void* x, void* feat, int N, int HW, int Cp, void* stream) {
+    HYB_CHECK_ARG(x && feat && N > 0 && HW > 0 && Cp % 32 == 0 && Cp > 0);
+    const long long total = (long long)N * (Cp / 8);
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(hyb_cdiv(total, 64)), dim3(64), 0, st, (const float*)x, (float*)feat, HW, Cp, total),
+        hipLaunchKernelGGL(gap_fwd_kernel<bf16>, dim3(hyb_cdiv(total, 64)), dim3(64), 0, st, (const bf16*)x, (bf16*)feat, HW, Cp, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hyb_gap_bwd(int dtype, const void* dfeat, void* dx, int N, int HW, int Cp, void* stream) {
+    HYB_CHECK_ARG(dfeat && dx && N > 0 && HW > 0 && Cp % 32 == 0 && Cp > 0);
+    const long long total = (long long)N * HW * (Cp / 8);
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const float*)dfeat, (float*)dx, HW, Cp, total),
+        hipLaunchKernelGGL(gap_bwd_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const bf16*)dfeat, (bf16*)dx, HW, Cp, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, void* stream) {
+    HYB_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C);
+    const long long total = (long long)N * H * W * Cp;
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, src, (float*)dst, C, H, W, Cp, total),
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, src, (bf16*)dst, C, H, W, Cp, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hyb_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, void* stream) {
+    HYB_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C);
+    const long long total = (long long)N * H * W * C;
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const float*)src, dst, C, H, W, Cp, total),
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const bf16*)src, dst, C, H, W, Cp, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hyb_cast_to_f32(int dtype, const void* src, float* dst, long long n, void* stream) {
+    HYB_CHECK_ARG(src && dst && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, st, (const float*)src, dst, n),
+        hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, dim3(stream_grid(n)), dim3(256), 0, st, (const bf16*)src, dst, n));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hyb_cast_from_f32(int dtype, const float* src, void* dst, long long n, void* stream) {
+    HYB_CHECK_ARG(src && dst && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    HYB_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, st, src, (float*)dst, n),
+        hipLaunchKernelGGL(cast_from_f32_kernel<bf16>, dim3(stream_grid(n)), dim3(256), 0, st, src, (bf16*)dst, n));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}

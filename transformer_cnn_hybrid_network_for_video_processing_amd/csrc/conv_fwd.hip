@@ -1,0 +1,396 @@
+// conv3x3 (stride 1, zero pad 1) as an implicit GEMM on the matrix cores, NHWC activations.
+// Replaces nn.Conv2d of UNet.py:58 (forward) and its autograd dgrad (with mode-1 packed weights).
+//
+// GEMM view per workgroup:  D[co][pixel] = sum_k  Wp[co][k] * patch[k][pixel],  k = (tap, ci)
+//   A operand = packed weights, held in REGISTERS for one (tap, 32-channel chunk) step
+//   B operand = 8 consecutive input channels of one pixel of a 4x4 pixel patch, read with one
+//               ds_read_b128 from an XOR-swizzled halo tile of the input staged in LDS
+//   a wave owns 8 patches (128 pixels) x NT*16 output channels (acc = 8*NT f32x4)
+// Workgroup = 4 waves = CB channel blocks x PG pixel groups; the grid walks image tiles
+// (persistent, grid-stride) and folds the BatchNorm batch statistics (sum, sum of squares per
+// output channel, UNet.py:59) into the epilogue from the fp32 accumulators.
+#include "hyb_common.h"
+
+namespace {
+
+template <int PG> struct TileGeom;
+template <> struct TileGeom<4> { static constexpr int PHP = 4, PWP = 8; };   // 16 x 32 pixels
+template <> struct TileGeom<2> { static constexpr int PHP = 4, PWP = 4; };   // 16 x 16 pixels
+template <> struct TileGeom<1> { static constexpr int PHP = 2, PWP = 4; };   //  8 x 16 pixels
+
+// swizzle of the 8-channel fragment slot inside a halo pixel (see DESIGN.md "conv LDS image"):
+// conflict-free ds_read_b128 for a 4x4-pixel patch at CK = 32, 64, >=128 (bf16).
+__device__ __forceinline__ int halo_swz(int hp, int hy, int spf) {
+    int sw = (hy & 1) << 1;
+    if (spf == 8) sw |= ((hp >> 1) & 1) << 2;
+    else if (spf >= 16) sw |= (hp & 3) << 2;
+    return sw & (spf - 1);
+}
+
+template <typename T, int NT, int CB, int PG, bool STATS>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                           T* __restrict__ y, float* __restrict__ stats,
+                                                           int N, int H, int W, int Cip, int Cop, int CK,
+                                                           int tilesX, int tilesY, int numTiles) {
+    constexpr int PHP = TileGeom<PG>::PHP, PWP = TileGeom<PG>::PWP;
+    constexpr int TH = 4 * PHP, TW = 4 * PWP, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
+    constexpr int MT = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* halo = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % CB, pg = wave / CB;
+    const int p = lane & 15, q = lane >> 4, py = p >> 2, px = p & 3;
+    const int SPF = CK >> 3;                               // fragment slots per halo pixel
+    const int co_base = blockIdx.y * (CB * NT * 16) + cb * (NT * 16);
+    const long long wrow = (long long)9 * Cip;
+
+    // this lane's A rows (one per co tile): permuted so that a lane ends up with NT*4 consecutive channels
+    const T* wlane[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        wlane[t] = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * wrow + 8 * q;
+
+    // halo pixel index (without tap offset) of this lane's pixel in each of its 8 patches
+    int hbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pidx = pg * MT + m;
+        hbase[m] = ((pidx / PWP) * 4 + py) * HW_ + (pidx % PWP) * 4 + px;
+    }
+
+    float s1[NT][4], s2[NT][4];
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+    }
+
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int n = tile / (tilesX * tilesY);
+        const int trem = tile - n * (tilesX * tilesY);
+        const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int cb0 = 0; cb0 < Cip; cb0 += CK) {
+            __syncthreads();
+            // ---- stage the halo tile for channels [cb0, cb0+CK): 8-channel units, zero outside the image
+            const int units = HP * SPF;
+            for (int u = tid; u < units; u += 256) {
+                const int hp = u / SPF, s = u - hp * SPF;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                Vec8<T> v;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + cb0 + 8 * s);
+                else
+                    v.zero();
+                v.store(halo + (long long)hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
+            }
+            __syncthreads();
+
+            const int nIt = (CK >> 5) * 9;
+            Frag<T> a_next[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) frag_load(a_next[t], wlane[t] + cb0);
+            for (int it = 0; it < nIt; ++it) {
+                const int chunk = it / 9, tap = it - chunk * 9;
+                Frag<T> a_cur[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_cur[t] = a_next[t];
+                if (it + 1 < nIt) {
+                    const int c2 = (it + 1) / 9, t2 = (it + 1) - c2 * 9;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) frag_load(a_next[t], wlane[t] + (long long)t2 * Cip + cb0 + c2 * 32);
+                }
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int hoff = kh * HW_ + kw;
+                const int s = chunk * 4 + q;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int hp = hbase[m] + hoff;
+                    const int hy = hp / HW_;
+                    Frag<T> b;
+                    frag_load(b, halo + (long long)hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a_cur[t], b, acc[m][t]);
+                }
+            }
+        }
+
+        // ---- epilogue: lane holds NT*4 consecutive channels of one pixel per patch
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int pidx = pg * MT + m;
+            const int gy = ty0 + (pidx / PWP) * 4 + py, gx = tx0 + (pidx % PWP) * 4 + px;
+            const bool valid = (gy < H) && (gx < W);
+            if (valid) {
+                T* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * (NT * 4);
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    Vec8<T> v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.set(j, acc[m][h8 * 2 + (j >> 2)][j & 3]);
+                    v.store(dst + h8 * 8);
+                }
+            }
+            if (STATS) {
+                const float vm = valid ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[m][t][r] * vm;
+                        s1[t][r] += v;
+                        s2[t][r] += v * v;
+                    }
+            }
+        }
+    }
+
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
+                if (p == 0) {
+                    const int co = co_base + q * (NT * 4) + t * 4 + r;
+                    atomicAdd(stats + co, a);
+                    atomicAdd(stats + Cop + co, b);
+                }
+            }
+    }
+}
+
+// First stage: x is the user's NCHW fp32 clip tensor [N,Ci,H,W], Ci <= 3, K = 9*Ci <= 27 padded to 32.
+// Bandwidth-shaped: one MFMA k-step per patch; the halo tile is staged as fp32 planes (coalesced along W)
+// and the patch fragment is gathered from LDS (k = tap*Ci + ci), converted to T in registers.
+template <typename T, int NT, bool STATS>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ x, const T* __restrict__ wp,
+                                                            T* __restrict__ y, float* __restrict__ stats,
+                                                            int N, int H, int W, int Ci, int Cop,
+                                                            int tilesX, int tilesY, int numTiles) {
+    constexpr int PG = 4;
+    constexpr int PHP = TileGeom<PG>::PHP, PWP = TileGeom<PG>::PWP;
+    constexpr int TH = 4 * PHP, TW = 4 * PWP, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
+    constexpr int MT = 8;
+    __shared__ float halo[3 * HP + 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int pg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4, py = p >> 2, px = p & 3;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int zero_idx = 3 * HP;
+    if (tid == 0) halo[zero_idx] = 0.f;
+
+    Frag<T> a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        frag_load(a[t], wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * 32 + 8 * q);
+
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        if (k < 9 * Ci) {
+            const int tap = k / Ci, ci = k - tap * Ci;
+            koff[j] = ci * HP + (tap / 3) * HW_ + (tap % 3);
+        } else {
+            koff[j] = -1;
+        }
+    }
+    int hbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pidx = pg * MT + m;
+        hbase[m] = ((pidx / PWP) * 4 + py) * HW_ + (pidx % PWP) * 4 + px;
+    }
+    float s1[NT][4], s2[NT][4];
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+    }
+
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int n = tile / (tilesX * tilesY);
+        const int trem = tile - n * (tilesX * tilesY);
+        const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+        __syncthreads();
+        for (int u = tid; u < Ci * HP; u += 256) {
+            const int ci = u / HP, hp = u - ci * HP;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((long long)(n * Ci + ci) * H + gy) * W + gx];
+            halo[u] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            Frag<T> b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = koff[j] >= 0 ? koff[j] + hbase[m] : zero_idx;
+                frag_set<T>(b, j, halo[idx]);
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mma32(a[t], b, f32x4{0.f, 0.f, 0.f, 0.f});
+
+            const int pidx = pg * MT + m;
+            const int gy = ty0 + (pidx / PWP) * 4 + py, gx = tx0 + (pidx % PWP) * 4 + px;
+            const bool valid = (gy < H) && (gx < W);
+            if (valid) {
+                T* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * (NT * 4);
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    Vec8<T> v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.set(j, acc[h8 * 2 + (j >> 2)][j & 3]);
+                    v.store(dst + h8 * 8);
+                }
+            }
+            if (STATS) {
+                const float vm = valid ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[t][r] * vm;
+                        s1[t][r] += v;
+                        s2[t][r] += v * v;
+                    }
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sa = group16_sum(s1[t][r]), sb = group16_sum(s2[t][r]);
+                if (p == 0) {
+                    const int co = co_base + q * (NT * 4) + t * 4 + r;
+                    atomicAdd(stats + co, sa);
+                    atomicAdd(stats + Cop + co, sb);
+                }
+            }
+    }
+}
+
+// w fp32 [Co,Ci,3,3] -> packed T (see hybrid_hip.h for the three modes); padded rows/cols are zero.
+template <typename T>
+__global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, int Cop, int Cip,
+                                   long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    if (mode == 0) {            // [Cop][9][Cip]
+        const int ci = (int)(i % Cip);
+        const int tap = (int)((i / Cip) % 9);
+        const int co = (int)(i / ((long long)9 * Cip));
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
+    } else if (mode == 1) {     // dgrad: rows = input channels: [Cip][9][Cop], tap flipped
+        const int co = (int)(i % Cop);
+        const int tap = (int)((i / Cop) % 9);
+        const int ci = (int)(i / ((long long)9 * Cop));
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
+    } else {                    // first layer: [Cop][32], k = tap*Ci + ci
+        const int k = (int)(i % 32);
+        const int co = (int)(i / 32);
+        if (co < Co && k < 9 * Ci) { const int tap = k / Ci, ci = k - tap * Ci; v = w[((long long)co * Ci + ci) * 9 + tap]; }
+    }
+    wp[i] = from_f32<T>(v);
+}
+
+template <typename T, int NT, int CB, int PG>
+int launch_conv(const T* x, const T* wp, T* y, float* stats, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
+    constexpr int TH = 4 * TileGeom<PG>::PHP, TW = 4 * TileGeom<PG>::PWP, HP = (TH + 2) * (TW + 2);
+    int CK = 32;
+    while (CK * 2 <= Cip && Cip % (CK * 2) == 0 && (size_t)HP * CK * 2 * sizeof(T) <= 64 * 1024) CK *= 2;
+    const size_t lds = (size_t)HP * CK * sizeof(T);
+    const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
+    const long long numTiles = (long long)N * tilesX * tilesY;
+    const int gy = Cop / (CB * NT * 16);
+    int gx = (int)(numTiles < 2048 / gy ? numTiles : 2048 / gy);
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, gy);
+    if (stats)
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, true>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop, CK,
+                           tilesX, tilesY, (int)numTiles);
+    else
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop, CK,
+                           tilesX, tilesY, (int)numTiles);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, int N, int H, int W, int Ci, int Cip, int Cop,
+               hipStream_t st) {
+    if (first) {
+        HYB_CHECK_ARG(Ci >= 1 && Ci <= 3);
+        constexpr int TH = 16, TW = 32;
+        const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
+        const long long numTiles = (long long)N * tilesX * tilesY;
+        const int nt = (Cop % 64 == 0) ? 4 : 2;
+        const int gy = Cop / (nt * 16);
+        int gx = (int)(numTiles < 2048 / gy ? numTiles : 2048 / gy);
+        if (gx < 1) gx = 1;
+        dim3 grid(gx, gy);
+#define HYB_FIRST(NT_, ST_) hipLaunchKernelGGL((conv3x3_first_kernel<T, NT_, ST_>), grid, dim3(256), 0, st, (const float*)x, (const T*)wp, \
+                                               (T*)y, stats, N, H, W, Ci, Cop, tilesX, tilesY, (int)numTiles)
+        if (nt == 4) { if (stats) HYB_FIRST(4, true); else HYB_FIRST(4, false); }
+        else         { if (stats) HYB_FIRST(2, true); else HYB_FIRST(2, false); }
+#undef HYB_FIRST
+        HYB_LAUNCH_CHECK();
+        return 0;
+    }
+    HYB_CHECK_ARG(Cip % 32 == 0);
+    if (Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
+    if (Cop % 128 == 0) return launch_conv<T, 4, 2, 2>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
+    if (Cop % 64 == 0) return launch_conv<T, 4, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
+    return launch_conv<T, 2, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
+}
+
+}  // namespace
+
+extern "C" long long hyb_conv_packed_elems(int first, int Cip, int Cop) {
+    return first ? (long long)Cop * 32 : (long long)Cop * 9 * Cip;
+}
+
+extern "C" int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, int Ci, int Cop, int Cip, void* stream) {
+    HYB_CHECK_ARG(w && wp && Co > 0 && Ci > 0 && Cop % 32 == 0 && Cop >= Co && mode >= 0 && mode <= 2);
+    if (mode == 2) HYB_CHECK_ARG(Ci <= 3);
+    else HYB_CHECK_ARG(Cip % 32 == 0 && Cip >= Ci);
+    const long long total = mode == 2 ? (long long)Cop * 32 : (long long)Cop * 9 * Cip;
+    const int blocks = hyb_cdiv(total, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HYB_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, mode, w, (float*)wp, Co, Ci, Cop, Cip, total);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, st, mode, w, (bf16*)wp, Co, Ci, Cop, Cip, total);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, int N, int H, int W, int Ci,
+                               int Cip, int Cop, void* stream) {
+    HYB_CHECK_ARG(x && wp && y && N > 0 && H > 0 && W > 0 && Cop > 0 && Cop % 32 == 0);
+    HYB_CHECK_ARG((long long)N * H * W * (Cop > Cip ? Cop : Cip) < (1ll << 40));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HYB_F32) return conv_fwd_t<float>(first, x, wp, y, stats, N, H, W, Ci, Cip, Cop, st);
+    if (dtype == HYB_BF16) return conv_fwd_t<bf16>(first, x, wp, y, stats, N, H, W, Ci, Cip, Cop, st);
+    return HYB_E_ARG;
+}

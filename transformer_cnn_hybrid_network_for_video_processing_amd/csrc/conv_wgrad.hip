@@ -1,0 +1,257 @@
+// Weight gradient of the 3x3 conv (autograd of nn.Conv2d, UNet.py:58) on the matrix cores.
+//
+//   dW[co][tap][ci] = sum over pixels  dy[pixel][co] * x[pixel + tap][ci]
+//
+// GEMM view: M = co, N = ci (per tap), K = pixels.  Both operands are channel-fastest (NHWC) in HBM,
+// but the contraction runs over PIXELS, so every MFMA fragment is a transposed read of an LDS tile:
+//   bf16: ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major)
+//   fp32: eight ds_read_b32 (parity mode only)
+// A workgroup owns one output block (64 co x CIT*16 ci x 9 taps, fp32 accumulators in registers) and
+// walks a strided subset of 8x16-pixel tiles; partial blocks go to fp32 slabs [S][Cop][9][Cip] that a
+// second kernel sums in a fixed order (bitwise reproducible; no float atomics).
+#include "hyb_common.h"
+
+namespace {
+
+constexpr int WG_TH = 8, WG_TW = 16, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2, WG_HP = WG_HH * WG_HW;   // halo 10 x 18
+constexpr int DY_COLS = 64, DY_STRIDE = DY_COLS + 16;          // row stride 80 elements: conflict-free tr reads
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// 8 pixel values of one channel column: pixels (row0, 4g + 0..3) and (row0 + 1, 4g + 0..3) of a tile image with
+// `stride` elements per pixel row-entry and `pitch` pixels per image row.  `base` points at (row0, 4g, channel 0).
+__device__ __forceinline__ void tr_frag(Frag<bf16>& f, const bf16* base, int stride, int pitch, int lane) {
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* a0 = base + qq * stride + 4 * pp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + pitch * stride));
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+}
+__device__ __forceinline__ void tr_frag(Frag<float>& f, const float* base, int stride, int pitch, int lane) {
+    const float* a0 = base + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f.v[j] = a0[j * stride];
+        f.v[4 + j] = a0[(pitch + j) * stride];
+    }
+}
+
+template <typename T, int CIT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ slab,
+                                                            int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles) {
+    constexpr int NCT = CIT;                       // co tiles per wave (waves = CIT ci tiles x 4/CIT co groups)
+    constexpr int XCOLS = CIT * 16, X_STRIDE = XCOLS + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* dyt = reinterpret_cast<T*>(smem_raw);                       // [128][DY_STRIDE]
+    T* xh = dyt + WG_TH * WG_TW * DY_STRIDE;                       // [180][X_STRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cit = wave % CIT, cog = wave / CIT;
+    const int g = lane >> 4;
+    const int nCiBlk = Cip / XCOLS;
+    const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * XCOLS;
+
+    f32x4 acc[9][NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int n = tile / (tilesX * tilesY);
+        const int trem = tile - n * (tilesX * tilesY);
+        const int ty0 = (trem / tilesX) * WG_TH, tx0 = (trem % tilesX) * WG_TW;
+        __syncthreads();
+        // stage dy tile: 128 pixels x 64 channels
+        for (int u = tid; u < WG_TH * WG_TW * (DY_COLS / 8); u += 256) {
+            const int pix = u >> 3, s = u & 7;
+            const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
+            Vec8<T> v;
+            if (gy < H && gx < W && co0 + 8 * s < Cop) v.load(dy + ((long long)(n * H + gy) * W + gx) * Cop + co0 + 8 * s);
+            else v.zero();
+            v.store(dyt + pix * DY_STRIDE + 8 * s);
+        }
+        // stage x halo: 180 pixels x XCOLS channels
+        for (int u = tid; u < WG_HP * (XCOLS / 8); u += 256) {
+            const int hp = u / (XCOLS / 8), s = u - hp * (XCOLS / 8);
+            const int hy = hp / WG_HW, hx = hp - hy * WG_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            Vec8<T> v;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + ci0 + 8 * s);
+            else v.zero();
+            v.store(xh + hp * X_STRIDE + 8 * s);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {           // 32 pixels per step: tile rows 2ks, 2ks+1
+            Frag<T> a[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                tr_frag(a[c], dyt + ((2 * ks) * WG_TW + 4 * g) * DY_STRIDE + (cog * NCT + c) * 16, DY_STRIDE, WG_TW, lane);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                Frag<T> b;
+                tr_frag(b, xh + ((2 * ks + kh) * WG_HW + 4 * g + kw) * X_STRIDE + cit * 16, X_STRIDE, WG_HW, lane);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[tap][c] = mma32(a[c], b, acc[tap][c]);
+            }
+        }
+    }
+    // D[row = co][col = ci]: lane holds ci = lane&15, co rows 4g + r
+    float* out = slab + (long long)blockIdx.x * Cop * 9 * Cip;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (cog * NCT + c) * 16 + 4 * g + r;
+                if (co < Cop) out[((long long)co * 9 + tap) * Cip + ci0 + cit * 16 + (lane & 15)] = acc[tap][c][r];
+            }
+}
+
+// First stage: x is NCHW fp32 [N,Ci,H,W], Ci <= 3; N-dimension of the GEMM is k = tap*Ci + ci (27 -> 32).
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_first_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                                  float* __restrict__ slab, int N, int H, int W, int Ci, int Cop,
+                                                                  int tilesX, int tilesY, int numTiles) {
+    constexpr int DYC = 32, DYS = DYC + 16;        // 32 channels per workgroup, stride 48
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[WG_TH * WG_TW * DYS * sizeof(float) + (3 * WG_HP + 4) * sizeof(float)];
+    T* dyt = reinterpret_cast<T*>(smem_raw);
+    float* xh = reinterpret_cast<float*>(smem_raw + WG_TH * WG_TW * DYS * sizeof(float));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt = wave & 1, ct = wave >> 1;
+    const int g = lane >> 4;
+    const int co0 = blockIdx.y * DYC;
+    const int zero_idx = 3 * WG_HP;
+    if (tid == 0) xh[zero_idx] = 0.f;
+    // this lane's k column
+    const int k = kt * 16 + (lane & 15);
+    int koff = -1;
+    if (k < 9 * Ci) { const int tap = k / Ci, ci = k - tap * Ci; koff = ci * WG_HP + (tap / 3) * WG_HW + (tap % 3); }
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int n = tile / (tilesX * tilesY);
+        const int trem = tile - n * (tilesX * tilesY);
+        const int ty0 = (trem / tilesX) * WG_TH, tx0 = (trem % tilesX) * WG_TW;
+        __syncthreads();
+        for (int u = tid; u < WG_TH * WG_TW * (DYC / 8); u += 256) {
+            const int pix = u >> 2, s = u & 3;
+            const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
+            Vec8<T> v;
+            if (gy < H && gx < W) v.load(dy + ((long long)(n * H + gy) * W + gx) * Cop + co0 + 8 * s);
+            else v.zero();
+            v.store(dyt + pix * DYS + 8 * s);
+        }
+        for (int u = tid; u < Ci * WG_HP; u += 256) {
+            const int ci = u / WG_HP, hp = u - ci * WG_HP;
+            const int hy = hp / WG_HW, hx = hp - hy * WG_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((long long)(n * Ci + ci) * H + gy) * W + gx];
+            xh[u] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            Frag<T> a, b;
+            tr_frag(a, dyt + ((2 * ks) * WG_TW + 4 * g) * DYS + ct * 16, DYS, WG_TW, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hidx = (2 * ks + (j >> 2)) * WG_HW + 4 * g + (j & 3);
+                frag_set<T>(b, j, xh[koff >= 0 ? koff + hidx : zero_idx]);
+            }
+            acc = mma32(a, b, acc);
+        }
+    }
+    float* out = slab + (long long)blockIdx.x * Cop * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(long long)(co0 + ct * 16 + 4 * g + r) * 32 + k] = acc[r];
+}
+
+// dw[co][ci][tap] = sum_s slab[s][co][tap][ci]  (first: slab[s][co][k], k = tap*Ci + ci)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int first, int Co, int Ci, int Cop,
+                                    int Cip, long long per_slab) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_slab) return;
+    int co, ci, tap;
+    if (first) {
+        const int k = (int)(i % 32);
+        co = (int)(i / 32);
+        if (k >= 9 * Ci || co >= Co) return;
+        tap = k / Ci; ci = k - tap * Ci;
+    } else {
+        ci = (int)(i % Cip);
+        tap = (int)((i / Cip) % 9);
+        co = (int)(i / ((long long)9 * Cip));
+        if (ci >= Ci || co >= Co) return;
+    }
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slab[(long long)k * per_slab + i];
+    dw[((long long)co * Ci + ci) * 9 + tap] = s;
+}
+
+struct WgradPlan { int S, gy, cit; long long per_slab; };
+
+inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
+    WgradPlan p;
+    const long long numTiles = (long long)N * hyb_cdiv(H, WG_TH) * hyb_cdiv(W, WG_TW);
+    if (first) { p.cit = 0; p.gy = Cop / 32; p.per_slab = (long long)Cop * 32; }
+    else { p.cit = (Cip % 64 == 0) ? 4 : 2; p.gy = ((Cop + 63) / 64) * (Cip / (p.cit * 16)); p.per_slab = (long long)Cop * 9 * Cip; }
+    long long s = 1024 / p.gy;
+    if (s < 1) s = 1;
+    if (s > numTiles) s = numTiles;
+    p.S = (int)s;
+    return p;
+}
+
+template <typename T>
+int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* ws,
+            size_t ws_bytes, hipStream_t st) {
+    const WgradPlan p = wgrad_plan(first, N, H, W, Cip, Cop);
+    if (ws_bytes < (size_t)p.S * p.per_slab * sizeof(float)) return HYB_E_WORKSPACE;
+    float* slab = (float*)ws;
+    const int tilesX = hyb_cdiv(W, WG_TW), tilesY = hyb_cdiv(H, WG_TH);
+    const int numTiles = N * tilesX * tilesY;
+    dim3 grid(p.S, p.gy);
+    if (first) {
+        hipLaunchKernelGGL(conv3x3_wgrad_first_kernel<T>, grid, dim3(256), 0, st, (const float*)x, (const T*)dy, slab, N, H, W, Ci, Cop, tilesX,
+                           tilesY, numTiles);
+    } else if (p.cit == 4) {
+        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (64 + 16)) * sizeof(T);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop, tilesX,
+                           tilesY, numTiles);
+    } else {
+        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (32 + 16)) * sizeof(T);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 2>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop, tilesX,
+                           tilesY, numTiles);
+    }
+    HYB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 256)), dim3(256), 0, st, slab, dw, p.S, first, Co, Ci, Cop, Cip, p.per_slab);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t hyb_conv3x3_wgrad_workspace(int first, int N, int H, int W, int Cip, int Cop) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cop <= 0 || Cop % 32 != 0 || (!first && (Cip <= 0 || Cip % 32 != 0))) return 0;
+    const WgradPlan p = wgrad_plan(first, N, H, W, Cip, Cop);
+    return (size_t)p.S * p.per_slab * sizeof(float);
+}
+
+extern "C" int hyb_conv3x3_wgrad(int dtype, int first, const void* x, const void* dy, float* dw, int N, int H, int W, int Ci, int Cip,
+                                 int Co, int Cop, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Co > 0 && Ci > 0 && Cop % 32 == 0 && Cop >= Co);
+    if (first) HYB_CHECK_ARG(Ci <= 3);
+    else HYB_CHECK_ARG(Cip % 32 == 0 && Cip >= Ci);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HYB_F32) return wgrad_t<float>(first, x, dy, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st);
+    if (dtype == HYB_BF16) return wgrad_t<bf16>(first, x, dy, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st);
+    return HYB_E_ARG;
+}

@@ -1,0 +1,130 @@
+// Shared device helpers for the gfx950 kernels: storage types, the MFMA "k32" step used by
+// every contraction, wave reductions and the counter-based dropout RNG.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hybrid_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define HYB_WAVE 64
+
+#define HYB_CHECK_ARG(cond) do { if (!(cond)) return HYB_E_ARG; } while (0)
+#define HYB_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static inline int hyb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+// ---------------------------------------------------------------------------------------
+// One lane's share of an MFMA operand for a 32-deep K step: 8 consecutive K elements of
+// one row (A) / column (B).  Lane l holds row/col (l & 15), K elements 8*(l >> 4) + j.
+//   bf16: exactly the operand of v_mfma_f32_16x16x32_bf16.
+//   fp32: eight v_mfma_f32_16x16x4_f32, MFMA j contracting K = {8q + j : q = 0..3}; the
+//         reduction order inside the 32-step is permuted but identical for A and B.
+// C/D: lane l holds column (l & 15), rows 4*(l >> 4) + r, r = 0..3.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ f32x4 mma32(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+}
+
+// load a fragment from 8 consecutive T (16-byte aligned for bf16, 16-byte aligned for fp32)
+__device__ __forceinline__ void frag_load(Frag<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+__device__ __forceinline__ void frag_zero(Frag<bf16>& f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (bf16)0.0f;
+}
+__device__ __forceinline__ void frag_zero(Frag<float>& f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = 0.0f;
+}
+template <typename T> __device__ __forceinline__ void frag_set(Frag<T>& f, int j, float v);
+template <> __device__ __forceinline__ void frag_set<bf16>(Frag<bf16>& f, int j, float v) { f.v[j] = (bf16)v; }
+template <> __device__ __forceinline__ void frag_set<float>(Frag<float>& f, int j, float v) { f.v[j] = v; }
+
+// 8 consecutive elements as a vector (global/LDS, 16-byte aligned for bf16; fp32 = 2 x 16 B)
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
+    __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16)x; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)0.0f;
+    }
+};
+template <> struct Vec8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+    __device__ __forceinline__ void set(int j, float x) { if (j < 4) a[j] = x; else b[j - 4] = x; }
+    __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = f32x4{0, 0, 0, 0}; }
+};
+
+// ---------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce across the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// dropout: stateless counter-based RNG.  keep(seed, idx) is a pure function so the
+// backward pass regenerates the forward mask from the same (seed, element index).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hyb_hash(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// returns the multiplier: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_mult(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    const float u = (float)(hyb_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}

@@ -1,0 +1,292 @@
+// LayerNorm + residual epilogue of TransformerEncoder.forward (TransformerEncoder.pyc src L116-117, L120-123):
+//   y = dropout_p( (LayerNorm(x) * gamma + beta + skip) * out_scale )
+// One wave per token row (D <= 2048), 8 features per lane per chunk, statistics by wave shuffles.
+// Also the classifier head (mean over T + Linear) and the cross-entropy loss: tiny, one kernel each.
+#include "hyb_common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 4;        // chunks of 8 features per lane: D <= 64*8*4 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              T* __restrict__ y, float* __restrict__ stats, int M, int D, float eps,
+                                                              float out_scale, float p_drop, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = D >> 3;
+    Vec8<T> xv[LN_MAXC];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            xv[c].load(x + (long long)row * D + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += xv[c].get(j);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = xv[c].get(j) - mean; var += dlt * dlt; }
+        }
+    }
+    var = wave_sum(var) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) { stats[row] = mean; stats[M + row] = rstd; }
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            Vec8<T> sk, o;
+            sk.load(skip + (long long)row * D + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = ch * 8 + j;
+                float v = ((xv[c].get(j) - mean) * rstd * gamma[col] + beta[col] + sk.get(j)) * out_scale;
+                if (p_drop > 0.f) v *= dropout_mult(seed, (unsigned long long)row * D + col, p_drop, inv_keep);
+                o.set(j, v);
+            }
+            o.store(y + (long long)row * D + ch * 8);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip,
+                                                              int accumulate_dskip, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int M, int D, float out_scale, float p_drop, unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const int nchunk = D >> 3;
+    const int total_waves = gridDim.x * 4;
+    float dg[LN_MAXC][8], db[LN_MAXC][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += total_waves) {
+        const float mean = stats[row], rstd = stats[M + row];
+        float gl[LN_MAXC][8], xh[LN_MAXC][8];      // g = d(ln_out) * gamma ; xhat
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                Vec8<T> dv, xv, ds;
+                dv.load(dy + (long long)row * D + ch * 8);
+                xv.load(x + (long long)row * D + ch * 8);
+                if (accumulate_dskip) ds.load(dskip + (long long)row * D + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = ch * 8 + j;
+                    float d = dv.get(j) * out_scale;
+                    if (p_drop > 0.f) d *= dropout_mult(seed, (unsigned long long)row * D + col, p_drop, inv_keep);
+                    const float xhat = (xv.get(j) - mean) * rstd;
+                    xh[c][j] = xhat;
+                    dg[c][j] += d * xhat;
+                    db[c][j] += d;
+                    const float g = d * gamma[col];
+                    gl[c][j] = g;
+                    s1 += g;
+                    s2 += g * xhat;
+                    ds.set(j, accumulate_dskip ? ds.get(j) + d : d);
+                }
+                ds.store(dskip + (long long)row * D + ch * 8);
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                Vec8<T> o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.set(j, rstd * (gl[c][j] - s1 - xh[c][j] * s2));
+                o.store(dx + (long long)row * D + ch * 8);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(dgamma + ch * 8 + j, dg[c][j]);
+                atomicAdd(dbeta + ch * 8 + j, db[c][j]);
+            }
+        }
+    }
+}
+
+// ---- head: logits[b][c] = bias[c] + sum_d mean_s(x[b][s][d]) * W[c][d] ------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ logits, int S, int D, int C) {
+    extern __shared__ float pooled[];          // [D]
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
+        pooled[d] = s / (float)S;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += pooled[d] * W[(long long)c * D + d];
+        s = wave_sum(s);
+        if (lane == 0) logits[b * C + c] = s + (bias ? bias[c] : 0.f);
+    }
+}
+// dx[b][s][d] = (1/S) sum_c dlogits[b][c] W[c][d]
+template <typename T>
+__global__ void head_bwd_dx_kernel(const float* __restrict__ W, const float* __restrict__ dlogits, T* __restrict__ dx, int S, int D, int C) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += dlogits[b * C + c] * W[(long long)c * D + d];
+        const T v = from_f32<T>(s / (float)S);
+        for (int t = 0; t < S; ++t) dx[((long long)b * S + t) * D + d] = v;
+    }
+}
+// dW[c][d] = sum_b dlogits[b][c] * mean_s x[b][s][d];  db[c] = sum_b dlogits[b][c]
+template <typename T>
+__global__ void head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ dW, float* __restrict__ db,
+                                   int B, int S, int D, int C) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < D) {
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                float s = 0.f;
+                for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
+                acc += dlogits[b * C + c] * (s / (float)S);
+            }
+            dW[(long long)c * D + d] = acc;
+        }
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x < C) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dlogits[b * C + threadIdx.x];
+        db[threadIdx.x] = s;
+    }
+}
+
+// ---- cross entropy (mean over the batch) --------------------------------------------------------------
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, float* __restrict__ loss, int B, int C) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
+        const long long t = target[b];
+        acc += (logf(s) + mx) - logits[b * C + (int)t];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, const float* __restrict__ dloss,
+                              float* __restrict__ dlogits, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
+    const float g = dloss[0] / (float)B;
+    const int t = (int)target[b];
+    for (int c = 0; c < C; ++c) dlogits[b * C + c] = g * (expf(logits[b * C + c] - mx) / s - (c == t ? 1.f : 0.f));
+}
+
+}  // namespace
+
+extern "C" int hyb_ln_residual_fwd(int dtype, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats,
+                                   int M, int D, float eps, float out_scale, float p_drop, unsigned long long seed, void* stream) {
+    HYB_CHECK_ARG(x && skip && gamma && beta && y && stats && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC && p_drop >= 0.f && p_drop < 1.f);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(hyb_cdiv(M, 4));
+    if (dtype == HYB_F32)
+        hipLaunchKernelGGL(ln_residual_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)skip, gamma, beta, (float*)y, stats, M, D, eps, out_scale, p_drop, seed);
+    else if (dtype == HYB_BF16)
+        hipLaunchKernelGGL(ln_residual_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)skip, gamma, beta, (bf16*)y, stats, M, D, eps, out_scale, p_drop, seed);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
+                                   int accumulate_dskip, float* dgamma, float* dbeta, int M, int D, float out_scale, float p_drop,
+                                   unsigned long long seed, void* stream) {
+    HYB_CHECK_ARG(dy && x && gamma && stats && dx && dskip && dgamma && dbeta && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC);
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = hyb_cdiv(M, 4);
+    if (blocks > 64) blocks = 64;
+    if (dtype == HYB_F32)
+        hipLaunchKernelGGL(ln_residual_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+    else if (dtype == HYB_BF16)
+        hipLaunchKernelGGL(ln_residual_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_head_fwd(int dtype, const void* x, const float* W, const float* b, float* logits, int B, int S, int D, int C, void* stream) {
+    HYB_CHECK_ARG(x && W && logits && B > 0 && S > 0 && D > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)D * sizeof(float);
+    if (dtype == HYB_F32) hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(256), lds, st, (const float*)x, W, b, logits, S, D, C);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16>, dim3(B), dim3(256), lds, st, (const bf16*)x, W, b, logits, S, D, C);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hyb_head_bwd(int dtype, const void* x, const float* W, const float* dlogits, void* dx, float* dW, float* db, int B, int S, int D,
+                            int C, void* stream) {
+    HYB_CHECK_ARG(x && W && dlogits && B > 0 && S > 0 && D > 0 && C > 0 && C <= 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != HYB_F32 && dtype != HYB_BF16) return HYB_E_ARG;
+    if (dx) {
+        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dx_kernel<float>, dim3(B), dim3(256), 0, st, W, dlogits, (float*)dx, S, D, C);
+        else hipLaunchKernelGGL(head_bwd_dx_kernel<bf16>, dim3(B), dim3(256), 0, st, W, dlogits, (bf16*)dx, S, D, C);
+        HYB_LAUNCH_CHECK();
+    }
+    if (dW) {
+        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 256)), dim3(256), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
+        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 256)), dim3(256), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
+        HYB_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int hyb_cross_entropy_fwd(const float* logits, const long long* target, float* loss, int B, int C, void* stream) {
+    HYB_CHECK_ARG(logits && target && loss && B > 0 && C > 0);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, B, C);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hyb_cross_entropy_bwd(const float* logits, const long long* target, const float* dloss, float* dlogits, int B, int C, void* stream) {
+    HYB_CHECK_ARG(logits && target && dloss && dlogits && B > 0 && C > 0);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(hyb_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, logits, target, dloss, dlogits, B, C);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,226 @@
+// nn.Linear forward/backward (TransformerEncoder.pyc src L12-15/L69/L87 projections, L107 FFN) as MFMA GEMMs.
+//
+// One kernel template computes  C[mo][no] = sum_r A(mo, r) * B(no, r)  for up to 3 independent groups
+// (blockIdx.z; used to run the Q, K and V projections in one launch).  Operand tiles are staged into LDS as
+// [row][r] (r contiguous, 32 deep) whatever the source orientation:
+//   normal source     : element (row, r) at p[row*ld + r]   (16-byte vector loads along r)
+//   transposed source : element (row, r) at p[r*ld + row]   (vector loads along row, scattered LDS writes)
+// fp32 sources (the master weights) are converted to T while staging.  Token counts (M = B*T = 128..512) are
+// small, so these GEMMs are latency-bound; tiles are 64x64 or 32x32 to spread them over more CUs.
+#include "hyb_common.h"
+
+namespace {
+
+struct GemmGroup {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;
+};
+struct GemmArgs {
+    GemmGroup g[3];
+    int Mo, No, R;          // output rows, output cols, reduction length
+    int lda, ldb, ldc;
+    int relu, accumulate;
+};
+
+constexpr int BK = 32, LDS_PAD = 8, LDS_ROW = BK + LDS_PAD;
+
+template <typename TS, typename T, bool TRANS, int ROWS>
+__device__ __forceinline__ void stage_tile(const TS* __restrict__ src, int ld, int row0, int nrows, int r0, int R, T* __restrict__ tile, int tid) {
+    if (!TRANS) {
+        if (tid < ROWS * 4) {
+            const int row = tid >> 2, seg = tid & 3;
+            const int gr = row0 + row, r = r0 + seg * 8;
+            Vec8<T> v;
+            if (gr < nrows && r + 8 <= R) {
+                Vec8<TS> s;
+                s.load(src + (long long)gr * ld + r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v.set(j, s.get(j));
+            } else {
+                v.zero();
+            }
+            v.store(tile + row * LDS_ROW + seg * 8);
+        }
+    } else {
+        if (tid < ROWS * 4) {
+            const int r = tid / (ROWS / 8), seg = tid % (ROWS / 8);
+            const int gr = row0 + seg * 8, rr = r0 + r;
+            Vec8<TS> s;
+            if (rr < R && gr + 8 <= nrows) s.load(src + (long long)rr * ld + gr);
+            else s.zero();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[(seg * 8 + j) * LDS_ROW + r] = from_f32<T>(s.get(j));
+        }
+    }
+}
+
+template <typename T, typename TA, typename TB, typename TC, bool TRANS_A, bool TRANS_B, int BM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
+    constexpr int BN = BM;
+    constexpr int WM = BM / 2, WN = BN / 2;            // per-wave sub-tile (2x2 waves)
+    constexpr int MT = WM / 16, NTT = WN / 16;
+    __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LDS_ROW];
+    const GemmGroup grp = args.g[blockIdx.z];
+    const TA* A = (const TA*)grp.A;
+    const TB* B = (const TB*)grp.B;
+    TC* C = (TC*)grp.C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int p = lane & 15, q = lane >> 4;
+
+    f32x4 acc[MT][NTT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int r0 = 0; r0 < args.R; r0 += BK) {
+        __syncthreads();
+        stage_tile<TA, T, TRANS_A, BM>(A, args.lda, m0, args.Mo, r0, args.R, As, tid);
+        stage_tile<TB, T, TRANS_B, BN>(B, args.ldb, n0, args.No, r0, args.R, Bs, tid);
+        __syncthreads();
+        Frag<T> a[MT], b[NTT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) frag_load(a[i], As + (wm * WM + i * 16 + p) * LDS_ROW + 8 * q);
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) frag_load(b[j], Bs + (wn * WN + j * 16 + p) * LDS_ROW + 8 * q);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTT; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) {
+            const int no = n0 + wn * WN + j * 16 + p;
+            if (no >= args.No) continue;
+            const float bias = grp.bias ? grp.bias[no] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = m0 + wm * WM + i * 16 + 4 * q + r;
+                if (mo >= args.Mo) continue;
+                float v = acc[i][j][r] + bias;
+                if (args.relu) v = fmaxf(v, 0.f);
+                TC* dst = C + (long long)mo * args.ldc + no;
+                if (args.accumulate) v += to_f32<TC>(*dst);
+                *dst = from_f32<TC>(v);
+            }
+        }
+}
+
+template <typename T, typename TA, typename TB, typename TC, bool TRANS_A, bool TRANS_B>
+int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
+    const long long tiles64 = (long long)hyb_cdiv(a.Mo, 64) * hyb_cdiv(a.No, 64) * groups;
+    if (tiles64 >= 128) {
+        dim3 grid(hyb_cdiv(a.No, 64), hyb_cdiv(a.Mo, 64), groups);
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 64>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid(hyb_cdiv(a.No, 32), hyb_cdiv(a.Mo, 32), groups);
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 32>), grid, dim3(256), 0, st, a);
+    }
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// dym = dy * (y > 0)
+template <typename T>
+__global__ void relu_mask_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        Vec8<T> a, b, o;
+        a.load(dy + i * 8);
+        b.load(y + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.set(j, b.get(j) > 0.f ? a.get(j) : 0.f);
+        o.store(out + i * 8);
+    }
+}
+
+// db[n] = sum_m dy[m][n]
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += to_f32<T>(dy[(long long)m * N + n]);
+    db[n] = s;
+}
+
+template <typename T>
+int linear_fwd_t(const void* x, int ldx, const float* W, const float* b, void* y, int M, int N, int K, int relu, hipStream_t st) {
+    GemmArgs a{};
+    a.g[0] = GemmGroup{x, W, y, b};
+    a.Mo = M; a.No = N; a.R = K; a.lda = ldx; a.ldb = K; a.ldc = N; a.relu = relu; a.accumulate = 0;
+    return launch_gemm<T, T, float, T, false, false>(a, 1, st);
+}
+
+template <typename T>
+int linear_bwd_t(const void* x, int ldx, const float* W, const void* y, const void* dy, void* dx, int accumulate_dx, float* dW, float* db,
+                 int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+    const T* dym = (const T*)dy;
+    if (relu) {
+        if (!y || !ws || ws_bytes < (size_t)M * N * sizeof(T)) return HYB_E_WORKSPACE;
+        const long long n8 = (long long)M * N / 8;
+        int blocks = hyb_cdiv(n8, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(relu_mask_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)ws, n8);
+        HYB_LAUNCH_CHECK();
+        dym = (const T*)ws;
+    }
+    if (dx) {        // dx[m][k] = sum_n dym[m][n] * W[n][k]
+        GemmArgs a{};
+        a.g[0] = GemmGroup{dym, W, dx, nullptr};
+        a.Mo = M; a.No = K; a.R = N; a.lda = N; a.ldb = K; a.ldc = ldx; a.relu = 0; a.accumulate = accumulate_dx;
+        int rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
+        if (rc) return rc;
+    }
+    if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]
+        GemmArgs a{};
+        a.g[0] = GemmGroup{dym, x, dW, nullptr};
+        a.Mo = N; a.No = K; a.R = M; a.lda = N; a.ldb = ldx; a.ldc = K; a.relu = 0; a.accumulate = 0;
+        int rc = launch_gemm<T, T, T, float, true, true>(a, 1, st);
+        if (rc) return rc;
+    }
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3(hyb_cdiv(N, 64)), dim3(64), 0, st, dym, db, M, N);
+        HYB_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Internal (same shared object): grouped forward used by the encoder to run Q, K, V in one launch.
+int hyb_linear_fwd_grouped3(int dtype, const void* const* x, const float* const* W, const float* const* b, void* const* y, int groups,
+                            int M, int N, int K, int relu, hipStream_t st) {
+    GemmArgs a{};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{x[i], W[i], y[i], b[i]};
+    a.Mo = M; a.No = N; a.R = K; a.lda = K; a.ldb = K; a.ldc = N; a.relu = relu; a.accumulate = 0;
+    if (dtype == HYB_F32) return launch_gemm<float, float, float, float, false, false>(a, groups, st);
+    if (dtype == HYB_BF16) return launch_gemm<bf16, bf16, float, bf16, false, false>(a, groups, st);
+    return HYB_E_ARG;
+}
+
+extern "C" int hyb_linear_fwd(int dtype, const void* x, int ldx, const float* W, const float* b, void* y, int M, int N, int K, int relu,
+                              void* stream) {
+    HYB_CHECK_ARG(x && W && y && M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldx >= K);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HYB_F32) return linear_fwd_t<float>(x, ldx, W, b, y, M, N, K, relu, st);
+    if (dtype == HYB_BF16) return linear_fwd_t<bf16>(x, ldx, W, b, y, M, N, K, relu, st);
+    return HYB_E_ARG;
+}
+
+extern "C" int hyb_linear_bwd(int dtype, const void* x, int ldx, const float* W, const void* y, const void* dy, void* dx, int accumulate_dx,
+                              float* dW, float* db, int M, int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(W && dy && M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldx >= K);
+    HYB_CHECK_ARG(!dW || x);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HYB_F32) return linear_bwd_t<float>(x, ldx, W, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
+    if (dtype == HYB_BF16) return linear_bwd_t<bf16>(x, ldx, W, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
+    return HYB_E_ARG;
+}
