@@ -71,9 +71,12 @@ int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, 
  * first=1: x is NCHW fp32 [N,Ci,H,W] with Ci<=3 (Cip ignored), wp packed with mode 2.
  * first=0: x is NHWC T [N,H,W,Cip], wp packed with mode 0 (or mode 1 for dgrad, with
  *          Cip/Cop exchanged by the caller).
- * stats: NULL, or fp32 [2][Cop] (sum, sum of squares per output channel over N*H*W),
- *        ACCUMULATED into (caller zeroes it). */
-int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats,
+ * stats: NULL, or fp32 [2][Cop] (sum, sum of squares per output channel over N*H*W), overwritten.
+ *        Computed from the fp32 accumulators as per-workgroup partial rows in `stats_partials`
+ *        (caller workspace of hyb_conv_stats_workspace(Cop) bytes) summed in a fixed order:
+ *        bitwise reproducible, no float atomics. */
+size_t hyb_conv_stats_workspace(int Cop);
+int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, float* stats_partials,
                     int N, int H, int W, int Ci, int Cip, int Cop, void* stream);
 
 /* BatchNorm2d statistics -> per-channel scale/shift (UNet.py:59; torch semantics:

@@ -65,7 +65,8 @@ def test_conv3x3_fwd_and_stats_exact(mode, ci, co, n, h, w):
     xin = x.cuda().contiguous() if first else to_nhwc(x, code, tdt, cip)
     y = torch.full((n, h, w, cop), 7.0, dtype=tdt, device="cuda")
     stats = torch.zeros(2, cop, device="cuda")
-    L().call("hyb_conv3x3_fwd", code, int(first), xin.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), n, h, w, ci, cip, cop, st())
+    part = torch.empty(L().query("hyb_conv_stats_workspace", cop), dtype=torch.uint8, device="cuda")
+    L().call("hyb_conv3x3_fwd", code, int(first), xin.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), part.data_ptr(), n, h, w, ci, cip, cop, st())
     got = to_nchw(y, code, co).cpu()
     assert torch.equal(got, want)
     if cop > co:
@@ -92,7 +93,7 @@ def test_conv3x3_dgrad_exact(mode, ci, co, n, h, w):
     L().call("hyb_conv_pack_weight", code, 1, wd.data_ptr(), wpd.data_ptr(), co, ci, cop, cip, st())
     dyn = to_nhwc(dy, code, tdt, cop)
     dx = torch.empty(n, h, w, cip, dtype=tdt, device="cuda")
-    L().call("hyb_conv3x3_fwd", code, 0, dyn.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, n, h, w, co, cop, cip, st())
+    L().call("hyb_conv3x3_fwd", code, 0, dyn.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, n, h, w, co, cop, cip, st())
     assert torch.equal(to_nchw(dx, code, ci).cpu(), want)
 
 

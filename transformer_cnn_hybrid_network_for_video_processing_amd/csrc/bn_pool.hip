@@ -208,26 +208,39 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __re
 }
 
 // ---- global average pool ------------------------------------------------------------------
+// one block per (frame, 32-octet slab): 32 octets x 8 pixel groups, LDS combine
 template <typename T>
-__global__ void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ feat, int HW, int Cp, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ feat, int HW, int Cp, int octBlocks) {
+    __shared__ float red[8][32][9];
     const int OCT = Cp >> 3;
-    const int oc = (int)(i % OCT);
-    const long long n = i / OCT;
+    const int n = blockIdx.x / octBlocks, ob = blockIdx.x % octBlocks;
+    const int ocl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int oc = ob * 32 + ocl;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const T* src = x + n * HW * Cp + oc * 8;
-    for (int p = 0; p < HW; ++p) {
-        Vec8<T> v;
-        v.load(src + (long long)p * Cp);
+    if (oc < OCT) {
+        const T* src = x + (long long)n * HW * Cp + oc * 8;
+        for (int p = grp; p < HW; p += 8) {
+            Vec8<T> v;
+            v.load(src + (long long)p * Cp);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v.get(j);
+            for (int j = 0; j < 8; ++j) acc[j] += v.get(j);
+        }
     }
-    Vec8<T> o;
-    const float inv = 1.0f / (float)HW;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.set(j, acc[j] * inv);
-    o.store(feat + n * Cp + oc * 8);
+    for (int j = 0; j < 8; ++j) red[grp][ocl][j] = acc[j];
+    __syncthreads();
+    if (grp == 0 && oc < OCT) {
+        Vec8<T> o;
+        const float inv = 1.0f / (float)HW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[k][ocl][j];
+            o.set(j, s * inv);
+        }
+        o.store(feat + (long long)n * Cp + oc * 8);
+    }
 }
 template <typename T>
 __global__ void gap_bwd_kernel(const T* __restrict__ dfeat, T* __restrict__ dx, int HW, int Cp, long long total) {
@@ -352,11 +365,11 @@ extern "C" int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const voi
 
 extern "C" int hyb_gap_fwd(int dtype, const void* x, void* feat, int N, int HW, int Cp, void* stream) {
     HYB_CHECK_ARG(x && feat && N > 0 && HW > 0 && Cp % 32 == 0 && Cp > 0);
-    const long long total = (long long)N * (Cp / 8);
+    const int octBlocks = hyb_cdiv(Cp / 8, 32);
     hipStream_t st = (hipStream_t)stream;
     HYB_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(hyb_cdiv(total, 64)), dim3(64), 0, st, (const float*)x, (float*)feat, HW, Cp, total),
-        hipLaunchKernelGGL(gap_fwd_kernel<bf16>, dim3(hyb_cdiv(total, 64)), dim3(64), 0, st, (const bf16*)x, (bf16*)feat, HW, Cp, total));
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(N * octBlocks), dim3(256), 0, st, (const float*)x, (float*)feat, HW, Cp, octBlocks),
+        hipLaunchKernelGGL(gap_fwd_kernel<bf16>, dim3(N * octBlocks), dim3(256), 0, st, (const bf16*)x, (bf16*)feat, HW, Cp, octBlocks));
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -157,17 +157,28 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__
     }
 
     if (STATS) {
+        // per-workgroup partial sums -> slab row blockIdx.x (summed in a fixed order by stats_reduce_kernel: reproducible)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][NT*16]
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
                 if (p == 0) {
-                    const int co = co_base + q * (NT * 4) + t * 4 + r;
-                    atomicAdd(stats + co, a);
-                    atomicAdd(stats + Cop + co, b);
+                    const int cl = q * (NT * 4) + t * 4 + r;
+                    red[(wave * 2 + 0) * (NT * 16) + cl] = a;
+                    red[(wave * 2 + 1) * (NT * 16) + cl] = b;
                 }
             }
+        __syncthreads();
+        for (int i = tid; i < CB * 2 * NT * 16; i += 256) {
+            const int cl = i % (NT * 16), which = (i / (NT * 16)) % 2, cbi = i / (2 * NT * 16);
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) acc += red[((g * CB + cbi) * 2 + which) * (NT * 16) + cl];
+            stats[((long long)blockIdx.x * 2 + which) * Cop + blockIdx.y * (CB * NT * 16) + cbi * (NT * 16) + cl] = acc;
+        }
     }
 }
 
@@ -276,17 +287,27 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
         }
     }
     if (STATS) {
+        __syncthreads();
+        float* red = halo;                                         // [4 waves][2][NT*16]
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sa = group16_sum(s1[t][r]), sb = group16_sum(s2[t][r]);
                 if (p == 0) {
-                    const int co = co_base + q * (NT * 4) + t * 4 + r;
-                    atomicAdd(stats + co, sa);
-                    atomicAdd(stats + Cop + co, sb);
+                    const int cl = q * (NT * 4) + t * 4 + r;
+                    red[(pg * 2 + 0) * (NT * 16) + cl] = sa;
+                    red[(pg * 2 + 1) * (NT * 16) + cl] = sb;
                 }
             }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 16; i += 256) {
+            const int cl = i % (NT * 16), which = i / (NT * 16);
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) acc += red[(g * 2 + which) * (NT * 16) + cl];
+            stats[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = acc;
+        }
     }
 }
 
@@ -315,8 +336,31 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __r
     wp[i] = from_f32<T>(v);
 }
 
+// stats[2][Cop] = sum over the G per-workgroup partial rows, fixed order: 32 columns x 8 row groups per block
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restrict__ part, float* __restrict__ stats, int G, int n) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int g = grp;
+        for (; g + 8 < G; g += 16) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 8) * n + i]; }
+        if (g < G) a0 += part[(long long)g * n + i];
+    }
+    red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][col];
+        stats[i] = s;
+    }
+}
+
+constexpr int MAX_STAT_PARTIALS = 512;
+
 template <typename T, int NT, int CB, int PG>
-int launch_conv(const T* x, const T* wp, T* y, float* stats, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
+int launch_conv(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
     constexpr int TH = 4 * TileGeom<PG>::PHP, TW = 4 * TileGeom<PG>::PWP, HP = (TH + 2) * (TW + 2);
     int CK = 32;
     while (CK * 2 <= Cip && Cip % (CK * 2) == 0 && (size_t)HP * CK * 2 * sizeof(T) <= 64 * 1024) CK *= 2;
@@ -324,13 +368,15 @@ int launch_conv(const T* x, const T* wp, T* y, float* stats, int N, int H, int W
     const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
     const int gy = Cop / (CB * NT * 16);
-    int gx = (int)(numTiles < 2048 / gy ? numTiles : 2048 / gy);
+    int gx = (int)(numTiles < MAX_STAT_PARTIALS ? numTiles : MAX_STAT_PARTIALS);
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
-    if (stats)
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, true>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop, CK,
+    if (stats) {
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop, CK,
                            tilesX, tilesY, (int)numTiles);
-    else
+        HYB_LAUNCH_CHECK();
+        hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+    } else
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop, CK,
                            tilesX, tilesY, (int)numTiles);
     HYB_LAUNCH_CHECK();
@@ -338,7 +384,7 @@ int launch_conv(const T* x, const T* wp, T* y, float* stats, int N, int H, int W
 }
 
 template <typename T>
-int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, int N, int H, int W, int Ci, int Cip, int Cop,
+int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, float* part, int N, int H, int W, int Ci, int Cip, int Cop,
                hipStream_t st) {
     if (first) {
         HYB_CHECK_ARG(Ci >= 1 && Ci <= 3);
@@ -347,22 +393,26 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
         const long long numTiles = (long long)N * tilesX * tilesY;
         const int nt = (Cop % 64 == 0) ? 4 : 2;
         const int gy = Cop / (nt * 16);
-        int gx = (int)(numTiles < 2048 / gy ? numTiles : 2048 / gy);
+        int gx = (int)(numTiles < MAX_STAT_PARTIALS ? numTiles : MAX_STAT_PARTIALS);
         if (gx < 1) gx = 1;
-        dim3 grid(gx, gy);
+            dim3 grid(gx, gy);
 #define HYB_FIRST(NT_, ST_) hipLaunchKernelGGL((conv3x3_first_kernel<T, NT_, ST_>), grid, dim3(256), 0, st, (const float*)x, (const T*)wp, \
-                                               (T*)y, stats, N, H, W, Ci, Cop, tilesX, tilesY, (int)numTiles)
+                                               (T*)y, part, N, H, W, Ci, Cop, tilesX, tilesY, (int)numTiles)
         if (nt == 4) { if (stats) HYB_FIRST(4, true); else HYB_FIRST(4, false); }
         else         { if (stats) HYB_FIRST(2, true); else HYB_FIRST(2, false); }
 #undef HYB_FIRST
         HYB_LAUNCH_CHECK();
+        if (stats) {
+            hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+            HYB_LAUNCH_CHECK();
+        }
         return 0;
     }
     HYB_CHECK_ARG(Cip % 32 == 0);
-    if (Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
-    if (Cop % 128 == 0) return launch_conv<T, 4, 2, 2>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
-    if (Cop % 64 == 0) return launch_conv<T, 4, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
-    return launch_conv<T, 2, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, N, H, W, Cip, Cop, st);
+    if (Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
+    if (Cop % 128 == 0) return launch_conv<T, 4, 2, 2>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
+    if (Cop % 64 == 0) return launch_conv<T, 4, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
+    return launch_conv<T, 2, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
 }
 
 }  // namespace
@@ -385,12 +435,16 @@ extern "C" int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* w
     return 0;
 }
 
-extern "C" int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, int N, int H, int W, int Ci,
-                               int Cip, int Cop, void* stream) {
+extern "C" size_t hyb_conv_stats_workspace(int Cop) { return Cop > 0 ? (size_t)MAX_STAT_PARTIALS * 2 * Cop * sizeof(float) : 0; }
+
+extern "C" int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, float* stats_partials, int N,
+                               int H, int W, int Ci, int Cip, int Cop, void* stream) {
     HYB_CHECK_ARG(x && wp && y && N > 0 && H > 0 && W > 0 && Cop > 0 && Cop % 32 == 0);
+    HYB_CHECK_ARG(!stats || stats_partials);
+    float* part = stats_partials;
     HYB_CHECK_ARG((long long)N * H * W * (Cop > Cip ? Cop : Cip) < (1ll << 40));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return conv_fwd_t<float>(first, x, wp, y, stats, N, H, W, Ci, Cip, Cop, st);
-    if (dtype == HYB_BF16) return conv_fwd_t<bf16>(first, x, wp, y, stats, N, H, W, Ci, Cip, Cop, st);
+    if (dtype == HYB_F32) return conv_fwd_t<float>(first, x, wp, y, stats, part, N, H, W, Ci, Cip, Cop, st);
+    if (dtype == HYB_BF16) return conv_fwd_t<bf16>(first, x, wp, y, stats, part, N, H, W, Ci, Cip, Cop, st);
     return HYB_E_ARG;
 }

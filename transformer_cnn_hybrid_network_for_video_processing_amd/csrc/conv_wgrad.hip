@@ -174,25 +174,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_first_kernel(const float* _
     for (int r = 0; r < 4; ++r) out[(long long)(co0 + ct * 16 + 4 * g + r) * 32 + k] = acc[r];
 }
 
-// dw[co][ci][tap] = sum_s slab[s][co][tap][ci]  (first: slab[s][co][k], k = tap*Ci + ci)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int first, int Co, int Ci, int Cop,
-                                    int Cip, long long per_slab) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_slab) return;
+// dw[co][ci][tap] = sum_s slab[s][co][tap][ci]  (first: slab[s][co][k], k = tap*Ci + ci); fixed summation order.
+// 32 outputs x 8 slab groups per block, LDS combine.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int first, int Co,
+                                                           int Ci, int Cop, int Cip, long long per_slab) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < per_slab) {
+        int k = grp;
+        for (; k + 8 < S; k += 16) { a0 += slab[(long long)k * per_slab + i]; a1 += slab[(long long)(k + 8) * per_slab + i]; }
+        if (k < S) a0 += slab[(long long)k * per_slab + i];
+    }
+    red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp != 0 || i >= per_slab) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][col];
     int co, ci, tap;
     if (first) {
-        const int k = (int)(i % 32);
+        const int kk = (int)(i % 32);
         co = (int)(i / 32);
-        if (k >= 9 * Ci || co >= Co) return;
-        tap = k / Ci; ci = k - tap * Ci;
+        if (kk >= 9 * Ci || co >= Co) return;
+        tap = kk / Ci; ci = kk - tap * Ci;
     } else {
         ci = (int)(i % Cip);
         tap = (int)((i / Cip) % 9);
         co = (int)(i / ((long long)9 * Cip));
         if (ci >= Ci || co >= Co) return;
     }
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += slab[(long long)k * per_slab + i];
     dw[((long long)co * Ci + ci) * 9 + tap] = s;
 }
 
@@ -203,7 +215,7 @@ inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
     const long long numTiles = (long long)N * hyb_cdiv(H, WG_TH) * hyb_cdiv(W, WG_TW);
     if (first) { p.cit = 0; p.gy = Cop / 32; p.per_slab = (long long)Cop * 32; }
     else { p.cit = (Cip % 64 == 0) ? 4 : 2; p.gy = ((Cop + 63) / 64) * (Cip / (p.cit * 16)); p.per_slab = (long long)Cop * 9 * Cip; }
-    long long s = 1024 / p.gy;
+    long long s = 512 / p.gy;
     if (s < 1) s = 1;
     if (s > numTiles) s = numTiles;
     p.S = (int)s;
@@ -232,7 +244,7 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
                            tilesY, numTiles);
     }
     HYB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 256)), dim3(256), 0, st, slab, dw, p.S, first, Co, Ci, Cop, Cip, p.per_slab);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(256), 0, st, slab, dw, p.S, first, Co, Ci, Cop, Cip, p.per_slab);
     HYB_LAUNCH_CHECK();
     return 0;
 }

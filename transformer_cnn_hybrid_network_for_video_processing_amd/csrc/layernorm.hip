@@ -117,16 +117,25 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
             }
         }
     }
+    // combine the block's 4 waves in LDS, then one atomic per feature per block
+    extern __shared__ float lnred[];          // [2][D]
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lnred[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                atomicAdd(dgamma + ch * 8 + j, dg[c][j]);
-                atomicAdd(dbeta + ch * 8 + j, db[c][j]);
+                atomicAdd(&lnred[ch * 8 + j], dg[c][j]);
+                atomicAdd(&lnred[D + ch * 8 + j], db[c][j]);
             }
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        atomicAdd(dgamma + i, lnred[i]);
+        atomicAdd(dbeta + i, lnred[D + i]);
     }
 }
 
@@ -162,22 +171,29 @@ __global__ void head_bwd_dx_kernel(const float* __restrict__ W, const float* __r
     }
 }
 // dW[c][d] = sum_b dlogits[b][c] * mean_s x[b][s][d];  db[c] = sum_b dlogits[b][c]
+// grid (D/64, C-chunks of 16): each thread owns one feature d, pools it once per clip, updates 16 class rows
 template <typename T>
 __global__ void head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ dW, float* __restrict__ db,
                                    int B, int S, int D, int C) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = blockIdx.y * 16;
     if (d < D) {
-        for (int c = 0; c < C; ++c) {
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) {
-                float s = 0.f;
-                for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
-                acc += dlogits[b * C + c] * (s / (float)S);
-            }
-            dW[(long long)c * D + d] = acc;
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
+            s /= (float)S;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c0 + c < C) acc[c] += dlogits[b * C + c0 + c] * s;
         }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c0 + c < C) dW[(long long)(c0 + c) * D + d] = acc[c];
     }
-    if (db && blockIdx.x == 0 && threadIdx.x < C) {
+    if (db && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += dlogits[b * C + threadIdx.x];
         db[threadIdx.x] = s;
@@ -239,11 +255,12 @@ extern "C" int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, con
     HYB_CHECK_ARG(dy && x && gamma && stats && dx && dskip && dgamma && dbeta && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC);
     hipStream_t st = (hipStream_t)stream;
     int blocks = hyb_cdiv(M, 4);
-    if (blocks > 64) blocks = 64;
+    if (blocks > 32) blocks = 32;
+    const size_t lnlds = 2 * (size_t)D * sizeof(float);
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL(ln_residual_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL(ln_residual_bwd_kernel<float>, dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL(ln_residual_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL(ln_residual_bwd_kernel<bf16>, dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
@@ -262,7 +279,7 @@ extern "C" int hyb_head_fwd(int dtype, const void* x, const float* W, const floa
 
 extern "C" int hyb_head_bwd(int dtype, const void* x, const float* W, const float* dlogits, void* dx, float* dW, float* db, int B, int S, int D,
                             int C, void* stream) {
-    HYB_CHECK_ARG(x && W && dlogits && B > 0 && S > 0 && D > 0 && C > 0 && C <= 256);
+    HYB_CHECK_ARG(x && W && dlogits && B > 0 && S > 0 && D > 0 && C > 0 && C <= 64);
     hipStream_t st = (hipStream_t)stream;
     if (dtype != HYB_F32 && dtype != HYB_BF16) return HYB_E_ARG;
     if (dx) {
@@ -271,8 +288,8 @@ extern "C" int hyb_head_bwd(int dtype, const void* x, const float* W, const floa
         HYB_LAUNCH_CHECK();
     }
     if (dW) {
-        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 256)), dim3(256), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
-        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 256)), dim3(256), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
+        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(64), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
+        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(64), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
         HYB_LAUNCH_CHECK();
     }
     return 0;

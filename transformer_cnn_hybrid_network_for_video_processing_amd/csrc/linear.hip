@@ -141,14 +141,23 @@ __global__ void relu_mask_kernel(const T* __restrict__ dy, const T* __restrict__
     }
 }
 
-// db[n] = sum_m dy[m][n]
+// db[n] = sum_m dy[m][n]: 32 columns x 8 row groups per block
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int M, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int M, int N) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + col;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += to_f32<T>(dy[(long long)m * N + n]);
-    db[n] = s;
+    if (n < N)
+        for (int m = grp; m < M; m += 8) s += to_f32<T>(dy[(long long)m * N + n]);
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][col];
+        db[n] = t;
+    }
 }
 
 template <typename T>
@@ -187,7 +196,7 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* y, const vo
         if (rc) return rc;
     }
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel<T>, dim3(hyb_cdiv(N, 64)), dim3(64), 0, st, dym, db, M, N);
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3(hyb_cdiv(N, 32)), dim3(256), 0, st, dym, db, M, N);
         HYB_LAUNCH_CHECK();
     }
     return 0;

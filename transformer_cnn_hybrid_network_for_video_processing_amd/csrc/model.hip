@@ -50,7 +50,7 @@ inline unsigned long long drop_seed(unsigned long long seed, int layer) { return
 // ----------------------------------------------------------------------------------------------------------
 extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es) + align256(2 * (size_t)Cop * 4);
+    return align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es) + align256(2 * (size_t)Cop * 4) + align256(hyb_conv_stats_workspace(Cop));
 }
 
 extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
@@ -65,9 +65,9 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
     char* ws = (char*)workspace;
     void* wp = ws;
     float* stats = (float*)(ws + align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es));
+    float* part = (float*)((char*)stats + align256(2 * (size_t)Cop * 4));
     HYB_TRY(hyb_conv_pack_weight(dtype, first ? 2 : 0, weight, wp, Co, Ci, Cop, Cip, stream));
-    if (training) HYB_HIP_TRY(hipMemsetAsync(stats, 0, 2 * (size_t)Cop * 4, (hipStream_t)stream));
-    HYB_TRY(hyb_conv3x3_fwd(dtype, first, x, wp, y_raw, training ? stats : nullptr, N, H, W, Ci, Cip, Cop, stream));
+    HYB_TRY(hyb_conv3x3_fwd(dtype, first, x, wp, y_raw, training ? stats : nullptr, part, N, H, W, Ci, Cip, Cop, stream));
     HYB_TRY(hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, (long long)N * H * W, Co, Cop,
                             scale_shift, mean_invstd, stream));
     HYB_TRY(hyb_bn_relu_pool_fwd(dtype, y_raw, scale_shift, pooled, N, H, W, Cop, stream));
@@ -108,7 +108,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     if (!first) {
         // dgrad = conv3x3 of the dense output gradient with the transposed, tap-flipped weights
         HYB_TRY(hyb_conv_pack_weight(dtype, 1, weight, wpd, Co, Ci, Cop, Cip, stream));
-        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wpd, dx, nullptr, N, H, W, Co, Cop, Cip, stream));
+        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wpd, dx, nullptr, nullptr, N, H, W, Co, Cop, Cip, stream));
     }
     return 0;
 }
