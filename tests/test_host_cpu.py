@@ -1,0 +1,125 @@
+"""CPU-only tests (no GPU): the C-ABI library loads and exports every symbol include/hybrid_hip.h declares, argument
+checks fail cleanly without touching a device, the drop-in modules keep the reference's constructor/state-dict contract,
+and the product path refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import transformer_cnn_hybrid_network_for_video_processing_amd as P
+from transformer_cnn_hybrid_network_for_video_processing_amd import _lib
+from oracle import hybrid_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from transformer_cnn_hybrid_network_for_video_processing_amd import build
+    build.build()
+    return _lib.lib
+
+
+def test_header_declares_expected_entry_points():
+    protos = _lib.parse_header()
+    for name in ["hyb_conv3x3_fwd", "hyb_conv3x3_wgrad", "hyb_convstage_fwd", "hyb_convstage_bwd", "hyb_bn_finalize",
+                 "hyb_bn_relu_pool_fwd", "hyb_linear_fwd", "hyb_linear_bwd", "hyb_attention_fwd", "hyb_attention_bwd",
+                 "hyb_ln_residual_fwd", "hyb_ln_residual_bwd", "hyb_encoder_fwd", "hyb_encoder_bwd", "hyb_head_fwd",
+                 "hyb_head_bwd", "hyb_cross_entropy_fwd", "hyb_cross_entropy_bwd", "hyb_gap_fwd", "hyb_gap_bwd"]:
+        assert name in protos, name
+    # every declaration in the header was understood by the parser
+    src = open(os.path.join(ROOT, "include", "hybrid_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    assert set(re.findall(r"\b(hyb_\w+)\s*\(", src)) == set(protos)
+
+
+def test_library_exports_every_declared_symbol(built):
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in built.protos:
+        assert hasattr(dll, name), f"{name} declared in include/hybrid_hip.h but not exported"
+    assert built.query("hyb_abi_version") == 1
+    assert built.query("hyb_dtype_size", 0) == 4 and built.query("hyb_dtype_size", 1) == 2 and built.query("hyb_dtype_size", 7) == -1
+    assert built.query("hyb_pad_channels", 3) == 32 and built.query("hyb_pad_channels", 64) == 64 and built.query("hyb_pad_channels", 65) == 96
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "hybrid_hip.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", " ", src, flags=re.S).lower()
+    assert "at::" not in src and "Tensor" not in src
+
+
+def test_argument_checks_fail_without_a_device(built):
+    """Bad arguments return HYB_E_ARG before any HIP call (so this runs on a GPU-less host)."""
+    assert built.raw("hyb_conv3x3_fwd")(0, 0, None, None, None, None, None, 1, 8, 8, 3, 32, 32, None) == -1
+    assert built.raw("hyb_linear_fwd")(1, None, 8, None, None, None, 4, 8, 8, 0, None) == -1
+    assert built.raw("hyb_attention_fwd")(1, None, None, None, None, None, None, 1, 4, 8, 2, 0.0, 0, None) == -1
+    assert built.raw("hyb_cross_entropy_fwd")(None, None, None, 1, 2, None) == -1
+    with pytest.raises(RuntimeError, match="argument check"):
+        built.call("hyb_gap_fwd", 1, None, None, 1, 1, 32, None)
+    # workspace / size queries are pure host functions
+    assert built.query("hyb_conv_packed_elems", 1, 0, 32) == 32 * 32
+    assert built.query("hyb_conv_packed_elems", 0, 64, 128) == 128 * 9 * 64
+    assert built.query("hyb_conv_stats_workspace", 64) > 0
+    assert built.query("hyb_conv3x3_wgrad_workspace", 0, 4, 16, 16, 32, 64) > 0
+    assert built.query("hyb_encoder_saved_bytes", 1, 8, 16, 512, 2048, 2, 8) > 0
+    assert built.query("hyb_encoder_workspace_bytes", 1, 8, 16, 512, 2048, 2, 8) > 0
+    assert built.query("hyb_convstage_bwd_workspace", 1, 0, 128, 28, 28, 128, 256) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    fresh = _lib._Lib()
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        fresh.call("hyb_abi_version")
+
+
+def test_module_contract_matches_reference_and_oracle():
+    m = P.TransformerCNNHybrid()                              # zero-argument constructible (Model.py:27 / FCT.py:302)
+    ref = R.TransformerCNNHybridRef()
+    assert sum(p.numel() for p in m.parameters()) == 6_827_304
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict())                       # oracle <-> product checkpoints interchange
+    ref.load_state_dict(m.state_dict())
+    for k in ("encoder1.enc1conv1.weight", "encoder1.enc1norm1.running_var", "encoder1.enc1norm1.num_batches_tracked",
+              "encoder.attention_layers.0.query_layer.weight", "encoder.feedforward_layers.1.2.bias", "encoder.layer_norm.0.weight"):
+        assert k in m.state_dict()
+    assert all(p.dtype == torch.float32 for p in m.parameters())
+    torch.optim.AdamW(m.parameters(), lr=1e-3)                # stock optimizer accepts them (Model.py:153)
+
+
+def test_encoder_ctor_contract():
+    with pytest.raises(ValueError, match="Input dimension must be divisible by number of heads. Here, Input dimension = 10"):
+        P.TransformerEncoder(10, 16, 1, 3, 0.0)
+    with pytest.raises(TypeError):
+        P.TransformerEncoder(8, 16)                           # five required positionals, as in the reference
+    enc = P.TransformerEncoder(8, 16, 2, 2, 0.1)
+    assert enc.attention_layers[0].dropoutLayer.p == 0.1 and enc.dropout == 0.1
+    assert enc.attention_layers[0]._attn_p() == 0.1
+    enc.eval()
+    assert enc.attention_layers[0]._attn_p() == 0.0           # quirk Q5: attention dropout follows train()/eval()
+    with pytest.raises(ValueError):
+        P.TransformerCNNHybrid(compute_dtype="fp16")
+
+
+def test_product_path_refuses_cpu_tensors():
+    m = P.TransformerCNNHybrid(cnn_channels=(32,), d_model=32, num_heads=2, num_layers=1, hidden_dim=32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 2, 3, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.TransformerEncoder(8, 16, 1, 2, 0.0)(torch.rand(1, 4, 8), None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.HybridCrossEntropyLoss()(torch.rand(2, 3), torch.tensor([0, 1]))
+    with pytest.raises(ValueError):
+        m(torch.rand(3, 16, 16))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "transformer_cnn_hybrid_network_for_video_processing_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "oracle" not in src, f
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        assert "oracle" not in open(os.path.join(pkg, "csrc", f)).read(), f
