@@ -27,14 +27,21 @@ __device__ __forceinline__ int halo_swz(int hp, int hy, int spf) {
     return sw & (spf - 1);
 }
 
-template <typename T, int NT, int CB, int PG, bool STATS>
-__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+// origin (in halo pixels) of patch m of pixel-group pg, relative to the tile origin
+template <int PG> __device__ __host__ constexpr int patch_row(int pg, int m) { return PG == 4 ? pg : (PG == 2 ? pg * 2 + m / 4 : m / 4); }
+template <int PG> __device__ __host__ constexpr int patch_col(int m) { return PG == 4 ? m : m % 4; }
+
+template <typename T, int NT, int CB, int PG, int CK, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                            T* __restrict__ y, float* __restrict__ stats,
-                                                           int N, int H, int W, int Cip, int Cop, int CK,
+                                                           int N, int H, int W, int Cip, int Cop,
                                                            int tilesX, int tilesY, int numTiles) {
     constexpr int PHP = TileGeom<PG>::PHP, PWP = TileGeom<PG>::PWP;
     constexpr int TH = 4 * PHP, TW = 4 * PWP, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
     constexpr int MT = 8;
+    constexpr int SPF = CK / 8;                            // 8-channel fragment slots per halo pixel
+    constexpr int NCHUNK = CK / 32;
+    static_assert(HW_ % 4 == 2, "swizzle derivation assumes halo width = 2 mod 4");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* halo = reinterpret_cast<T*>(smem_raw);
 
@@ -43,9 +50,9 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave % CB, pg = wave / CB;
     const int p = lane & 15, q = lane >> 4, py = p >> 2, px = p & 3;
-    const int SPF = CK >> 3;                               // fragment slots per halo pixel
     const int co_base = blockIdx.y * (CB * NT * 16) + cb * (NT * 16);
-    const long long wrow = (long long)9 * Cip;
+    const int nCblk = Cip / CK;
+    const long long wrow = (long long)9 * Cip;            // packed row: [Cip/32][9][32]
 
     // this lane's A rows (one per co tile): permuted so that a lane ends up with NT*4 consecutive channels
     const T* wlane[NT];
@@ -53,26 +60,40 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__
     for (int t = 0; t < NT; ++t)
         wlane[t] = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * wrow + 8 * q;
 
-    // halo pixel index (without tap offset) of this lane's pixel in each of its 8 patches
-    int hbase[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int pidx = pg * MT + m;
-        hbase[m] = ((pidx / PWP) * 4 + py) * HW_ + (pidx % PWP) * 4 + px;
+    // LDS element offset of this lane's pixel in patch 0 of its wave (tap (0,0)); patches m and taps add constants
+    const int lane_el = ((patch_row<PG>(pg, 0) * 4 + py) * HW_ + px) * CK;
+    // swizzle of the fragment slot: depends on the lane and the tap only (patch origins are multiples of 4 pixels)
+    const int sw_row = py, sw_col = 2 * py + px;
+
+    // BN sums of this workgroup live in LDS behind the halo image: [2][CB*NT*16] floats, updated once per tile
+    float* wgstat = reinterpret_cast<float*>(smem_raw + (size_t)HP * CK * sizeof(T));
+    if (STATS) {
+        for (int i = tid; i < 2 * CB * NT * 16; i += 256) wgstat[i] = 0.f;
     }
 
-    float s1[NT][4], s2[NT][4];
-    if (STATS) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
-    }
+    auto stage = [&](int n, int ty0, int tx0, int cb0) {
+        for (int u = tid; u < HP * SPF; u += 256) {
+            const int hp = u / SPF, s = u - hp * SPF;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            Vec8<T> v;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + cb0 + 8 * s);
+            else
+                v.zero();
+            v.store(halo + hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
+        }
+    };
 
     for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
         const int n = tile / (tilesX * tilesY);
         const int trem = tile - n * (tilesX * tilesY);
         const int ty0 = (trem / tilesX) * TH, tx0 = (trem % tilesX) * TW;
+
+        // first channel block: staged while the accumulators are dead
+        __syncthreads();
+        stage(n, ty0, tx0, 0);
+        __syncthreads();
 
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -80,58 +101,60 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int cb0 = 0; cb0 < Cip; cb0 += CK) {
-            __syncthreads();
-            // ---- stage the halo tile for channels [cb0, cb0+CK): 8-channel units, zero outside the image
-            const int units = HP * SPF;
-            for (int u = tid; u < units; u += 256) {
-                const int hp = u / SPF, s = u - hp * SPF;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-                Vec8<T> v;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + cb0 + 8 * s);
-                else
-                    v.zero();
-                v.store(halo + (long long)hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
+        for (int cblk = 0; cblk < nCblk; ++cblk) {
+            if (cblk > 0) {
+                __syncthreads();
+                stage(n, ty0, tx0, cblk * CK);
+                __syncthreads();
             }
-            __syncthreads();
-
-            const int nIt = (CK >> 5) * 9;
-            Frag<T> a_next[NT];
+#pragma unroll 1
+            for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+                const T* wbase[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) frag_load(a_next[t], wlane[t] + cb0);
-            for (int it = 0; it < nIt; ++it) {
-                const int chunk = it / 9, tap = it - chunk * 9;
-                Frag<T> a_cur[NT];
+                for (int t = 0; t < NT; ++t) wbase[t] = wlane[t] + (long long)(cblk * NCHUNK + chunk) * (9 * 32);
+                constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;      // bf16: prefetch the next tap's weights; fp32: single buffer
+                Frag<T> a[NBUF][NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a_cur[t] = a_next[t];
-                if (it + 1 < nIt) {
-                    const int c2 = (it + 1) / 9, t2 = (it + 1) - c2 * 9;
+                for (int t = 0; t < NT; ++t) frag_load(a[0][t], wbase[t]);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) frag_load(a_next[t], wlane[t] + (long long)t2 * Cip + cb0 + c2 * 32);
-                }
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const int hoff = kh * HW_ + kw;
-                const int s = chunk * 4 + q;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap % 3;
+                    if (NBUF == 2 && tap + 1 < 9) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int hp = hbase[m] + hoff;
-                    const int hy = hp / HW_;
-                    Frag<T> b;
-                    frag_load(b, halo + (long long)hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
+                        for (int t = 0; t < NT; ++t) frag_load(a[(tap + 1) % NBUF][t], wbase[t] + (tap + 1) * 32);
+                    }
+                    if (NBUF == 1 && tap > 0) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a_cur[t], b, acc[m][t]);
+                        for (int t = 0; t < NT; ++t) frag_load(a[0][t], wbase[t] + tap * 32);
+                    }
+                    int sw = ((sw_row + kh) & 1) << 1;
+                    if (SPF == 8) sw |= (((sw_col + 2 * kh + kw) >> 1) & 1) << 2;
+                    if (SPF >= 16) sw |= ((sw_col + 2 * kh + kw) & 3) << 2;
+                    const T* bptr = halo + lane_el + (kh * HW_ + kw) * CK + (((chunk * 4 + q) ^ sw) << 3);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        Frag<T> b;
+                        frag_load(b, bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a[tap % NBUF][t], b, acc[m][t]);
+                    }
                 }
             }
         }
 
         // ---- epilogue: lane holds NT*4 consecutive channels of one pixel per patch
+        const bool full = (ty0 + TH <= H) && (tx0 + TW <= W);
+        float s1[NT][4], s2[NT][4];
+        if (STATS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int pidx = pg * MT + m;
-            const int gy = ty0 + (pidx / PWP) * 4 + py, gx = tx0 + (pidx % PWP) * 4 + px;
-            const bool valid = (gy < H) && (gx < W);
+            const int gy = ty0 + patch_row<PG>(pg, m) * 4 + py, gx = tx0 + patch_col<PG>(m) * 4 + px;
+            const bool valid = full || ((gy < H) && (gx < W));
             if (valid) {
                 T* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * (NT * 4);
 #pragma unroll
@@ -141,43 +164,40 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const T* __restrict__
                     for (int j = 0; j < 8; ++j) v.set(j, acc[m][h8 * 2 + (j >> 2)][j & 3]);
                     v.store(dst + h8 * 8);
                 }
+                if (STATS) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[m][t][r];
+                            s1[t][r] += v;
+                            s2[t][r] = fmaf(v, v, s2[t][r]);
+                        }
+                }
             }
-            if (STATS) {
-                const float vm = valid ? 1.f : 0.f;
+        }
+        if (STATS) {
+            // fold the 16 pixel lanes, then one LDS add per channel per wave (fixed wave order is not needed: fp32 adds of
+            // per-wave partials commute up to rounding; the cross-workgroup sum below is in a fixed order)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[m][t][r] * vm;
-                        s1[t][r] += v;
-                        s2[t][r] += v * v;
+                for (int r = 0; r < 4; ++r) {
+                    const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
+                    if (p == 0) {
+                        const int cl = cb * (NT * 16) + q * (NT * 4) + t * 4 + r;
+                        atomicAdd(&wgstat[cl], a);
+                        atomicAdd(&wgstat[CB * NT * 16 + cl], b);
                     }
-            }
+                }
         }
     }
 
     if (STATS) {
-        // per-workgroup partial sums -> slab row blockIdx.x (summed in a fixed order by stats_reduce_kernel: reproducible)
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][NT*16]
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
-                if (p == 0) {
-                    const int cl = q * (NT * 4) + t * 4 + r;
-                    red[(wave * 2 + 0) * (NT * 16) + cl] = a;
-                    red[(wave * 2 + 1) * (NT * 16) + cl] = b;
-                }
-            }
-        __syncthreads();
-        for (int i = tid; i < CB * 2 * NT * 16; i += 256) {
-            const int cl = i % (NT * 16), which = (i / (NT * 16)) % 2, cbi = i / (2 * NT * 16);
-            float acc = 0.f;
-#pragma unroll
-            for (int g = 0; g < PG; ++g) acc += red[((g * CB + cbi) * 2 + which) * (NT * 16) + cl];
-            stats[((long long)blockIdx.x * 2 + which) * Cop + blockIdx.y * (CB * NT * 16) + cbi * (NT * 16) + cl] = acc;
+        for (int i = tid; i < 2 * CB * NT * 16; i += 256) {
+            const int which = i / (CB * NT * 16), cl = i % (CB * NT * 16);
+            stats[((long long)blockIdx.x * 2 + which) * Cop + blockIdx.y * (CB * NT * 16) + cl] = wgstat[i];
         }
     }
 }
@@ -318,15 +338,19 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __r
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     float v = 0.f;
-    if (mode == 0) {            // [Cop][9][Cip]
-        const int ci = (int)(i % Cip);
-        const int tap = (int)((i / Cip) % 9);
+    if (mode == 0) {            // [Cop][Cip/32][9][32]
+        const int c32 = (int)(i % 32);
+        const int tap = (int)((i / 32) % 9);
+        const int chunk = (int)((i / 288) % (Cip / 32));
         const int co = (int)(i / ((long long)9 * Cip));
+        const int ci = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
-    } else if (mode == 1) {     // dgrad: rows = input channels: [Cip][9][Cop], tap flipped
-        const int co = (int)(i % Cop);
-        const int tap = (int)((i / Cop) % 9);
+    } else if (mode == 1) {     // dgrad: rows = input channels: [Cip][Cop/32][9][32], tap flipped
+        const int c32 = (int)(i % 32);
+        const int tap = (int)((i / 32) % 9);
+        const int chunk = (int)((i / 288) % (Cop / 32));
         const int ci = (int)(i / ((long long)9 * Cop));
+        const int co = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
     } else {                    // first layer: [Cop][32], k = tap*Ci + ci
         const int k = (int)(i % 32);
@@ -359,28 +383,46 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restri
 
 constexpr int MAX_STAT_PARTIALS = 512;
 
-template <typename T, int NT, int CB, int PG>
-int launch_conv(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
+template <typename T, int NT, int CB, int PG, int CK>
+int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
     constexpr int TH = 4 * TileGeom<PG>::PHP, TW = 4 * TileGeom<PG>::PWP, HP = (TH + 2) * (TW + 2);
-    int CK = 32;
-    while (CK * 2 <= Cip && Cip % (CK * 2) == 0 && (size_t)HP * CK * 2 * sizeof(T) <= 64 * 1024) CK *= 2;
-    const size_t lds = (size_t)HP * CK * sizeof(T);
+    const size_t lds = (size_t)HP * CK * sizeof(T) + 2 * CB * NT * 16 * sizeof(float);
     const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
     const int gy = Cop / (CB * NT * 16);
     int gx = (int)(numTiles < MAX_STAT_PARTIALS ? numTiles : MAX_STAT_PARTIALS);
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
+    if (lds > 64 * 1024) {
+        const void* f = stats ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>;
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     if (stats) {
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop, CK,
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
         HYB_LAUNCH_CHECK();
         hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
-    } else
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop, CK,
+    } else {
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
+    }
     HYB_LAUNCH_CHECK();
     return 0;
+}
+
+// CK = channels staged per LDS halo image: the largest of {128, 64, 32} that divides Cip and keeps the image <= ~48 KB (bf16)
+template <typename T, int NT, int CB, int PG>
+int launch_conv(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
+    constexpr int ES = (int)sizeof(T);
+    if constexpr (PG == 1) {
+        if (Cip % 128 == 0 && ES == 2) return launch_conv_ck<T, NT, CB, PG, 128>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
+        if (Cip % 64 == 0) return launch_conv_ck<T, NT, CB, PG, 64>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
+    }
+    if constexpr (PG == 2) {
+        if (Cip % 64 == 0 && ES == 2) return launch_conv_ck<T, NT, CB, PG, 64>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
+    }
+    return launch_conv_ck<T, NT, CB, PG, 32>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
 }
 
 template <typename T>
