@@ -1,0 +1,544 @@
+// Stage 1 (Conv3x3 -> BatchNorm -> ReLU -> MaxPool on the NCHW fp32 clip frames, UNet.py:58-60 + UNet.py:13) WITHOUT ever
+// writing the full-resolution conv output: with Ci <= 4 the conv is K = 9*4 = 36 deep, far cheaper to recompute on the
+// matrix cores than to store and re-read (411 MB of bf16 per step at config 2).  One kernel template, four modes:
+//   MODE 0  conv -> per-channel sum / sum of squares (BN batch statistics)                      reads x
+//   MODE 1  conv -> scale/shift -> ReLU -> 2x2 max (lane shuffles) -> pooled NHWC output          reads x, writes pooled
+//   MODE 2  conv -> argmax/ReLU routing of dpooled -> sum(dy), sum(dy*xhat)                        reads x, dpooled
+//   MODE 3  conv -> dense BN-backward gradient tile in LDS -> weight gradient (contraction over pixels)  reads x, dpooled
+// A workgroup walks 8x32-pixel tiles.  The fp32 halo (10x34 pixels, prefetched one tile ahead into registers) is converted
+// to T and expanded into an im2col matrix P[pixel][k = tap*4 + c] in LDS; P rows feed the conv MFMA (k contiguous) and
+// P columns feed the wgrad MFMA through transposed LDS reads, so no scalar gathers are needed.
+#include "hyb_common.h"
+
+namespace {
+
+constexpr int S1_TH = 8, S1_TW = 32, S1_HW = S1_TW + 2, S1_HH = S1_TH + 2, S1_HP = S1_HH * S1_HW;   // halo 10 x 34 = 340 pixels
+constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
+constexpr int S1_KP = 64, S1_PS = S1_KP + 8;   // padded K and P row stride (elements)
+constexpr int S1_MAXPART = 1024;
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;
+
+// 4 channels of one pixel as one 8-byte (bf16) / 16-byte (fp32) LDS access
+template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
+
+__device__ __forceinline__ void tr_frag_s1(Frag<bf16>& f, const bf16* base, int stride, int second, int lane) {
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* a0 = base + qq * stride + 4 * pp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_s1*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_s1*)(a0 + second * stride));
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+}
+__device__ __forceinline__ void tr_frag_s1(Frag<float>& f, const float* base, int stride, int second, int lane) {
+    const float* a0 = base + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f.v[j] = a0[j * stride];
+        f.v[4 + j] = a0[(second + j) * stride];
+    }
+}
+
+struct S1Args {
+    const float* x;          // [N,Ci,H,W] fp32
+    const void* wp;          // packed weights T [Cop][64], k = tap*4 + c
+    const float* ss;         // scale/shift [2][Cop]
+    const float* mi;         // mean/invstd [2][Cop]
+    const float* gamma;      // [Co]
+    const float* sums;       // [2][Cop] (sum dy, sum dy*xhat)
+    const void* dp;          // dpooled NHWC T [N,H/2,W/2,Cop]
+    void* pooled;            // pooled NHWC T
+    float* part;             // per-workgroup partial rows (stats / sums / wgrad slabs)
+    int N, H, W, Ci, Co, Cop;
+    int training;
+    float inv_count;
+    int tilesX, tilesY, numTiles;
+    int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
+};
+
+constexpr int S1_IW = S1_TW + 8;               // image row in LDS: columns tx0-4 .. tx0+35 (aligned float4 segments)
+constexpr int S1_IMG = S1_HH * S1_IW;          // 400 pixels x 4 channels
+
+// 8 K-elements of one pixel's im2col row for k-step 0 (taps 2q, 2q+1) or k-step 1 (tap 8 for q == 0, else zero),
+// read straight from the halo image [row][col][4 channels]
+__device__ __forceinline__ void s1_bfrag(Frag<bf16>& f, const bf16* img, int base_el, int q, int step) {
+    if (step == 0) {
+        const int t0 = 2 * q, t1 = 2 * q + 1;
+        const Quad<bf16> a = *reinterpret_cast<const Quad<bf16>*>(img + base_el + ((t0 / 3) * S1_IW + t0 % 3) * 4);
+        const Quad<bf16> b = *reinterpret_cast<const Quad<bf16>*>(img + base_el + ((t1 / 3) * S1_IW + t1 % 3) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { f.v[c] = a.v[c]; f.v[4 + c] = b.v[c]; }
+    } else {
+        Quad<bf16> a = *reinterpret_cast<const Quad<bf16>*>(img + base_el + (2 * S1_IW + 2) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { f.v[c] = q == 0 ? a.v[c] : (bf16)0.0f; f.v[4 + c] = (bf16)0.0f; }
+    }
+}
+__device__ __forceinline__ void s1_bfrag(Frag<float>& f, const float* img, int base_el, int q, int step) {
+    if (step == 0) {
+        const int t0 = 2 * q, t1 = 2 * q + 1;
+        const Quad<float> a = *reinterpret_cast<const Quad<float>*>(img + base_el + ((t0 / 3) * S1_IW + t0 % 3) * 4);
+        const Quad<float> b = *reinterpret_cast<const Quad<float>*>(img + base_el + ((t1 / 3) * S1_IW + t1 % 3) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { f.v[c] = a.v[c]; f.v[4 + c] = b.v[c]; }
+    } else {
+        const Quad<float> a = *reinterpret_cast<const Quad<float>*>(img + base_el + (2 * S1_IW + 2) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { f.v[c] = q == 0 ? a.v[c] : 0.f; f.v[4 + c] = 0.f; }
+    }
+}
+
+// A wave owns one 8x8-pixel block = 16 pooling windows.  MFMA column (lane & 15) = window (wy, wx); MFMA j = window position
+// (jy, jx), so a lane holds all four values of its window for NT*4 channels: max / first-argmax are register-local.
+template <typename T, int NT, int MODE>
+__global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* img = reinterpret_cast<T*>(smem_raw);                       // [10][40][4]
+    T* P = img + S1_IMG * 4;                                       // MODE 3: im2col [256][S1_PS]
+    constexpr int DS = NT * 16 + 8;
+    T* dyt = P + S1_NPIX * S1_PS;                                  // MODE 3: [256][DS]
+    float* wgstat = reinterpret_cast<float*>(MODE == 3 ? (dyt + S1_NPIX * DS) : P);   // [2][NT*16] (modes 0, 2)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4, wy = p >> 2, wx = p & 3;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int H = a.H, W = a.W, Ci = a.Ci, Cop = a.Cop;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const T* wp = (const T*)a.wp;
+
+    if (MODE == 3) {   // zero the im2col padding columns (k >= 36) once; they are never written again
+        for (int i = tid; i < S1_NPIX * (S1_PS - 36); i += 256) {
+            const int pix = i / (S1_PS - 36), k = 36 + i % (S1_PS - 36);
+            P[pix * S1_PS + k] = from_f32<T>(0.f);
+        }
+    }
+    if (MODE == 0 || MODE == 2) {
+        for (int i = tid; i < 2 * NT * 16; i += 256) wgstat[i] = 0.f;
+    }
+
+    Frag<T> w0[NT], w1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const T* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
+        frag_load(w0[t], row);
+        frag_load(w1[t], row + 32);
+    }
+    float c_sc[NT][4], c_sh[NT][4], c_mean[NT][4], c_inv[NT][4], c_k[NT][4], c_m1[NT][4], c_m2[NT][4];
+    if (MODE >= 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = co_base + q * (NT * 4) + t * 4 + r;
+                c_sc[t][r] = a.ss[ch]; c_sh[t][r] = a.ss[Cop + ch];
+                if (MODE >= 2) { c_mean[t][r] = a.mi[ch]; c_inv[t][r] = a.mi[Cop + ch]; }
+                if (MODE == 3) {
+                    c_k[t][r] = (ch < a.Co ? a.gamma[ch] : 0.f) * a.mi[Cop + ch];
+                    c_m1[t][r] = a.training ? a.sums[ch] * a.inv_count : 0.f;
+                    c_m2[t][r] = a.training ? a.sums[Cop + ch] * a.inv_count : 0.f;
+                }
+            }
+    }
+    float acc1[NT][4], acc2[NT][4];           // MODE 0: sum / sum sq ; MODE 2: sum(dy) / sum(dy*xhat)   (per lane, all tiles)
+    if (MODE == 0 || MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc1[t][r] = 0.f; acc2[t][r] = 0.f; }
+    }
+    f32x4 wacc[3][NT];                        // MODE 3: dW[co tile][k tile] partials of this wave
+    if (MODE == 3) {
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // halo prefetch: thread u < 100 owns (row = u / 10, segment = u % 10): 4 consecutive pixels x up to 4 channels
+    f32x4 pf[4];
+    auto prefetch = [&](int tile) {
+        if (tid >= 100) return;
+        const int n = tile / (a.tilesX * a.tilesY);
+        const int trem = tile - n * (a.tilesX * a.tilesY);
+        const int ty0 = (trem / a.tilesX) * S1_TH, tx0 = (trem % a.tilesX) * S1_TW;
+        const int row = tid / 10, seg = tid - row * 10;
+        const int gy = ty0 + row - 1, gx0 = tx0 - 4 + 4 * seg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < Ci && gy >= 0 && gy < H) {
+                const float* src = a.x + ((long long)(n * Ci + c) * H + gy) * W + gx0;
+                if (a.vec_ok) {
+                    if (gx0 >= 0 && gx0 + 3 < W) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (gx0 + i >= 0 && gx0 + i < W) v[i] = src[i];
+                }
+            }
+            pf[c] = v;
+        }
+    };
+    if ((int)blockIdx.x < a.numTiles) prefetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+        const int n = tile / (a.tilesX * a.tilesY);
+        const int trem = tile - n * (a.tilesX * a.tilesY);
+        const int ty0 = (trem / a.tilesX) * S1_TH, tx0 = (trem % a.tilesX) * S1_TW;
+        __syncthreads();                                   // previous tile done with img / P / dyt
+        if (tid < 100) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Quad<T> qv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                *reinterpret_cast<Quad<T>*>(img + (tid * 4 + i) * 4) = qv;       // pixel (row, 4*seg + i) = tid*4 + i
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.numTiles) prefetch(tile + gridDim.x);      // in flight under this tile's work
+        if (MODE == 3) {   // im2col for the wgrad B operand: pixel tid, 9 taps x 4 channels
+            const int ty = tid >> 5, tx = tid & 31;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                *reinterpret_cast<Quad<T>*>(P + tid * S1_PS + tap * 4) =
+                    *reinterpret_cast<const Quad<T>*>(img + ((ty + tap / 3) * S1_IW + tx + 3 + tap % 3) * 4);
+        }
+
+        // ---- conv of this wave's 8x8 block: 4 window positions x NT channel tiles
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ly = 2 * wy + (j >> 1), lx = wave * 8 + 2 * wx + (j & 1);
+            const int base_el = (ly * S1_IW + lx + 3) * 4;                     // tap (0,0) of this pixel
+            Frag<T> b0, b1;
+            s1_bfrag(b0, img, base_el, q, 0);
+            s1_bfrag(b1, img, base_el, q, 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[j][t] = mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[j][t] = mma32(w1[t], b1, acc[j][t]);
+            }
+        }
+        const int gy0 = ty0 + 2 * wy, gx0 = tx0 + wave * 8 + 2 * wx;          // window origin
+        const int oy = gy0 >> 1, ox = gx0 >> 1;
+        const bool win_ok = oy < Ho && ox < Wo;
+
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = (gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W;
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { acc1[t][r] += acc[j][t][r]; acc2[t][r] = fmaf(acc[j][t][r], acc[j][t][r], acc2[t][r]); }
+                }
+            }
+        }
+        if (MODE == 1) {
+            if (win_ok) {
+                T* dst = (T*)a.pooled + ((long long)(n * Ho + oy) * Wo + ox) * Cop + co_base + q * (NT * 4);
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    Vec8<T> o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int t = h8 * 2 + (e >> 2), r = e & 3;
+                        const float sc = c_sc[t][r], sh = c_sh[t][r];
+                        const float m = fmaxf(fmaxf(acc[0][t][r] * sc + sh, acc[1][t][r] * sc + sh),
+                                              fmaxf(acc[2][t][r] * sc + sh, acc[3][t][r] * sc + sh));
+                        o.set(e, fmaxf(m, 0.f));
+                    }
+                    o.store(dst + h8 * 8);
+                }
+            }
+        }
+        if (MODE >= 2) {
+            const T* dsrc = (const T*)a.dp + ((long long)(n * Ho + oy) * Wo + ox) * Cop + co_base + q * (NT * 4);
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) {
+                Vec8<T> g;
+                if (win_ok) g.load(dsrc + h8 * 8); else g.zero();
+                Vec8<T> o[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int t = h8 * 2 + (e >> 2), r = e & 3;
+                    const float sc = c_sc[t][r], sh = c_sh[t][r];
+                    // first maximum in torch's window scan order (0,0),(0,1),(1,0),(1,1); ReLU gate on the maximum
+                    float vmax = acc[0][t][r] * sc + sh;
+                    int am = 0;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        const float v = acc[j][t][r] * sc + sh;
+                        if (v > vmax) { vmax = v; am = j; }
+                    }
+                    const float dy = (vmax > 0.f && win_ok) ? g.get(e) : 0.f;
+                    if (MODE == 2) {
+                        const float ysel = am == 0 ? acc[0][t][r] : am == 1 ? acc[1][t][r] : am == 2 ? acc[2][t][r] : acc[3][t][r];
+                        acc1[t][r] += dy;
+                        acc2[t][r] += dy * (ysel - c_mean[t][r]) * c_inv[t][r];
+                    }
+                    if (MODE == 3) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool valid = (gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W;
+                            const float xhat = (acc[j][t][r] - c_mean[t][r]) * c_inv[t][r];
+                            o[j].set(e, valid ? c_k[t][r] * ((am == j ? dy : 0.f) - c_m1[t][r] - xhat * c_m2[t][r]) : 0.f);
+                        }
+                    }
+                }
+                if (MODE == 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pix = (2 * wy + (j >> 1)) * S1_TW + wave * 8 + 2 * wx + (j & 1);
+                        o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
+                    }
+                }
+            }
+        }
+        if (MODE == 3) {
+            __syncthreads();
+            // dW[co][k] += sum over this wave's 2 tile rows (32 pixels = one k32 step each)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = wave * 2 + rr;
+                Frag<T> af[NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) tr_frag_s1(af[c], dyt + (row * S1_TW + 4 * q) * DS + c * 16, DS, 16, lane);
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    Frag<T> bf;
+                    tr_frag_s1(bf, P + (row * S1_TW + 4 * q) * S1_PS + kt * 16, S1_PS, 16, lane);
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf, wacc[kt][c]);
+                }
+            }
+        }
+    }
+
+    if (MODE == 0 || MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = group16_sum(acc1[t][r]), s2 = group16_sum(acc2[t][r]);
+                if (p == 0) {
+                    atomicAdd(&wgstat[q * (NT * 4) + t * 4 + r], s1);
+                    atomicAdd(&wgstat[NT * 16 + q * (NT * 4) + t * 4 + r], s2);
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 16; i += 256) {
+            const int which = i / (NT * 16), cl = i % (NT * 16);
+            a.part[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = wgstat[i];
+        }
+    }
+    if (MODE == 3) {
+        // combine the 4 waves through LDS (reusing P/dyt), then one slab row per workgroup: slab[co][k], k = tap*4 + c (48 kept)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(P);                  // [4][NT*16][48]
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * (NT * 16) + c * 16 + 4 * q + r) * 48 + kt * 16 + p] = wacc[kt][c][r];
+        __syncthreads();
+        float* out = a.part + (long long)blockIdx.x * Cop * 48;
+        for (int i = tid; i < NT * 16 * 48; i += 256) {
+            const float v = (red[i] + red[NT * 16 * 48 + i]) + (red[2 * NT * 16 * 48 + i] + red[3 * NT * 16 * 48 + i]);
+            out[(long long)(co_base + i / 48) * 48 + i % 48] = v;
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum_s slab[s][co][tap*4 + ci]; fixed order (32 outputs x 8 slab groups per block)
+__global__ __launch_bounds__(256) void s1_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
+                                                              int Cop) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long per = (long long)Cop * 48;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < per) {
+        int k = grp;
+        for (; k + 8 < S; k += 16) { a0 += slab[(long long)k * per + i]; a1 += slab[(long long)(k + 8) * per + i]; }
+        if (k < S) a0 += slab[(long long)k * per + i];
+    }
+    red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp != 0 || i >= per) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][col];
+    const int kk = (int)(i % 48), co = (int)(i / 48);
+    const int tap = kk >> 2, ci = kk & 3;
+    if (co < Co && tap < 9 && ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = s;
+}
+
+// packed first-layer weights for this path: T [Cop][64], k = tap*4 + c
+template <typename T>
+__global__ void s1_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % 64), co = (int)(i / 64);
+    const int tap = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (co < Co && tap < 9 && c < Ci) v = w[((long long)co * Ci + c) * 9 + tap];
+    wp[i] = from_f32<T>(v);
+}
+
+// partial rows -> [n] (fixed order), shared with conv_fwd.hip's stats reduce in spirit
+__global__ __launch_bounds__(256) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int g = grp;
+        for (; g + 8 < G; g += 16) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 8) * n + i]; }
+        if (g < G) a0 += part[(long long)g * n + i];
+    }
+    red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][col];
+        out[i] = s;
+    }
+}
+
+template <typename T, int NT, int MODE>
+size_t s1_lds_bytes() {
+    size_t el = (size_t)S1_IMG * 4;
+    if (MODE == 3) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
+    return el * sizeof(T) + 2 * NT * 16 * sizeof(float) + 64;
+}
+
+template <typename T, int NT, int MODE>
+int s1_launch(S1Args a, int grid_x, hipStream_t st) {
+    const size_t lds = s1_lds_bytes<T, NT, MODE>();
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)stage1_kernel<T, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(grid_x, a.Cop / (NT * 16));
+    hipLaunchKernelGGL((stage1_kernel<T, NT, MODE>), grid, dim3(256), lds, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int MODE>
+int s1_dispatch(const S1Args& a, int grid_x, hipStream_t st) {
+    if (a.Cop % 64 == 0) return s1_launch<T, 4, MODE>(a, grid_x, st);
+    return s1_launch<T, 2, MODE>(a, grid_x, st);
+}
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ---- internal entry points used by hyb_convstage_{fwd,bwd} when first = 1 ----------------------------------------------
+size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    return al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * 2 * Cop * 4);
+}
+size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    return al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * Cop * 48 * 4);
+}
+
+static int s1_grid(long long numTiles) {
+    long long g = numTiles < S1_MAXPART ? numTiles : S1_MAXPART;
+    return (int)(g < 1 ? 1 : g);
+}
+
+template <typename T>
+static int stage1_fwd_t(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co,
+                        int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st) {
+    const size_t es = sizeof(T);
+    char* ws = (char*)workspace;
+    T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
+    float* stats = (float*)ws;                   ws += al256(2 * (size_t)Cop * 4);
+    float* part = (float*)ws;
+    const long long total = (long long)Cop * 64;
+    hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
+    HYB_LAUNCH_CHECK();
+    S1Args a{};
+    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.pooled = pooled; a.part = part;
+    a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
+    a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
+    a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const long long numTiles = (long long)N * a.tilesX * a.tilesY;
+    a.numTiles = (int)numTiles;
+    const int gx = s1_grid(numTiles);
+    if (training) {
+        int rc = s1_dispatch<T, 0>(a, gx, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+        HYB_LAUNCH_CHECK();
+    }
+    int rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, (long long)N * H * W, Co, Cop,
+                             scale_shift, mean_invstd, (void*)st);
+    if (rc) return rc;
+    return s1_dispatch<T, 1>(a, gx, st);
+}
+
+template <typename T>
+static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
+                        const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
+                        float* dbeta, void* workspace, hipStream_t st) {
+    const size_t es = sizeof(T);
+    char* ws = (char*)workspace;
+    T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
+    float* sums = (float*)ws;                    ws += al256(2 * (size_t)Cop * 4);
+    float* part = (float*)ws;
+    const long long total = (long long)Cop * 64;
+    hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
+    HYB_LAUNCH_CHECK();
+    S1Args a{};
+    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = sums; a.dp = dpooled; a.part = part;
+    a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
+    a.inv_count = 1.0f / (float)((long long)N * H * W);
+    a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
+    a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const long long numTiles = (long long)N * a.tilesX * a.tilesY;
+    a.numTiles = (int)numTiles;
+    const int gx = s1_grid(numTiles);
+    int rc = s1_dispatch<T, 2>(a, gx, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, sums, gx, 2 * Cop);
+    HYB_LAUNCH_CHECK();
+    rc = s1_dispatch<T, 3>(a, gx, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(s1_wgrad_reduce_kernel, dim3(hyb_cdiv((long long)Cop * 48, 32)), dim3(256), 0, st, part, dweight, gx, Co, Ci, Cop);
+    HYB_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        // dbeta = sum dy, dgamma = sum dy*xhat
+        if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
+        if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + Cop, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
+    }
+    return 0;
+}
+
+int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
+                   void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st) {
+    if (Ci < 1 || Ci > 4) return HYB_E_ARG;
+    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, workspace, st);
+    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, workspace, st);
+    return HYB_E_ARG;
+}
+
+int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
+                   const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
+                   float* dbeta, void* workspace, hipStream_t st) {
+    if (Ci < 1 || Ci > 4) return HYB_E_ARG;
+    if (dtype == HYB_F32) return stage1_bwd_t<float>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, workspace, st);
+    if (dtype == HYB_BF16) return stage1_bwd_t<bf16>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, workspace, st);
+    return HYB_E_ARG;
+}

@@ -9,6 +9,9 @@
 // small, so these GEMMs are latency-bound; tiles are 64x64 or 32x32 to spread them over more CUs.
 #include "hyb_common.h"
 
+int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st);
+
 namespace {
 
 struct GemmGroup {
@@ -128,6 +131,108 @@ int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Skinny-M GEMM for the token side (M = B*T = 128..512 rows):  C[mo][no] = sum_r A[mo][r] * B[no][r], A and B both
+// of type T, r-contiguous (weights pre-converted/pre-transposed once per step by convert_weights_kernel).
+// No LDS staging and no barrier in the K loop: every lane loads its MFMA fragments (16 B) straight from global
+// (operands are L2-resident: <= 4 MB), the 4 waves of a workgroup split K (wave w takes k-steps w, w+4, ...), and the
+// partial 32x32 tiles are combined through LDS once at the end.  Grid = (No/32, Mo/32, groups).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, typename TC>
+__global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
+    __shared__ float red[4][32][33];
+    const GemmGroup grp = args.g[blockIdx.z];
+    const T* A = (const T*)grp.A;
+    const T* B = (const T*)grp.B;
+    TC* C = (TC*)grp.C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const T* arow[2];
+    const T* brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = m0 + i * 16 + p; if (r > args.Mo - 1) r = args.Mo - 1;
+        int c = n0 + i * 16 + p; if (c > args.No - 1) c = args.No - 1;
+        arow[i] = A + (long long)r * args.lda + 8 * q;
+        brow[i] = B + (long long)c * args.ldb + 8 * q;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int R = args.R;
+#pragma unroll 4
+    for (int k0 = wave * 32; k0 < R; k0 += 128) {
+        Frag<T> a[2], b[2];
+        const bool ok = (k0 + 8 * q + 8) <= R;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (ok) { frag_load(a[i], arow[i] + k0); frag_load(b[i], brow[i] + k0); }
+            else { frag_zero(a[i]); frag_zero(b[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * q + r][j * 16 + p] = acc[i][j][r];
+    __syncthreads();
+    // 1024 outputs / 256 threads: thread -> row (tid / 8), 4 consecutive columns
+    const int row = tid >> 3, c0 = (tid & 7) * 4;
+    const int mo = m0 + row;
+    if (mo >= args.Mo) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int no = n0 + c0 + c;
+        if (no >= args.No) continue;
+        float v = (red[0][row][c0 + c] + red[1][row][c0 + c]) + (red[2][row][c0 + c] + red[3][row][c0 + c]);
+        if (grp.bias) v += grp.bias[no];
+        if (args.relu) v = fmaxf(v, 0.f);
+        TC* dst = C + (long long)mo * args.ldc + no;
+        if (args.accumulate) v += to_f32<TC>(*dst);
+        *dst = from_f32<TC>(v);
+    }
+}
+
+// fp32 master weight W[N][K] -> T copy Wc[N][K] and T transpose Wt[K][N] (one 32x32 tile per block, grouped over blockIdx.z)
+struct ConvertArgs {
+    const float* W[8];
+    void* Wc[8];
+    void* Wt[8];
+    int N[8], K[8];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z;
+    const int N = a.N[g], K = a.K[g];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    if (n0 >= N || k0 >= K) return;
+    const float* W = a.W[g];
+    T* Wc = (T*)a.Wc[g];
+    T* Wt = (T*)a.Wt[g];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        float v = 0.f;
+        if (n < N && k < K) { v = W[(long long)n * K + k]; Wc[(long long)n * K + k] = from_f32<T>(v); }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        if (n < N && k < K) Wt[(long long)k * N + n] = from_f32<T>(tile[tx][r]);
+    }
+}
+
 // dym = dy * (y > 0)
 template <typename T>
 __global__ void relu_mask_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, long long n8) {
@@ -169,8 +274,8 @@ int linear_fwd_t(const void* x, int ldx, const float* W, const float* b, void* y
 }
 
 template <typename T>
-int linear_bwd_t(const void* x, int ldx, const float* W, const void* y, const void* dy, void* dx, int accumulate_dx, float* dW, float* db,
-                 int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx, float* dW,
+                 float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
     const T* dym = (const T*)dy;
     if (relu) {
         if (!y || !ws || ws_bytes < (size_t)M * N * sizeof(T)) return HYB_E_WORKSPACE;
@@ -181,7 +286,13 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* y, const vo
         HYB_LAUNCH_CHECK();
         dym = (const T*)ws;
     }
-    if (dx) {        // dx[m][k] = sum_n dym[m][n] * W[n][k]
+    if (dx && Wt) {  // dx[m][k] = sum_n dym[m][n] * Wt[k][n]  (pre-transposed T weights: skinny NT GEMM, no LDS staging)
+        const void* A_[1] = {dym};
+        const void* B_[1] = {Wt};
+        void* C_[1] = {dx};
+        int rc = hyb_gemm_nt(sizeof(T) == 4 ? HYB_F32 : HYB_BF16, 1, A_, B_, C_, nullptr, 0, M, K, N, N, N, ldx, 0, accumulate_dx, st);
+        if (rc) return rc;
+    } else if (dx) { // dx[m][k] = sum_n dym[m][n] * W[n][k]
         GemmArgs a{};
         a.g[0] = GemmGroup{dym, W, dx, nullptr};
         a.Mo = M; a.No = K; a.R = N; a.lda = N; a.ldb = K; a.ldc = ldx; a.relu = 0; a.accumulate = accumulate_dx;
@@ -203,6 +314,61 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* y, const vo
 }
 
 }  // namespace
+
+// Internal: linear backward with pre-transposed T weights for the dx product
+int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
+                      float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (dtype == HYB_F32) return linear_bwd_t<float>(x, ldx, W, Wt, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, ws, ws_bytes, st);
+    if (dtype == HYB_BF16) return linear_bwd_t<bf16>(x, ldx, W, Wt, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, ws, ws_bytes, st);
+    return HYB_E_ARG;
+}
+
+// Internal (same shared object): skinny NT GEMM on pre-converted T operands, up to 3 groups.
+int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st) {
+    if (groups < 1 || groups > 3 || R % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return HYB_E_ARG;
+    GemmArgs a{};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr};
+    a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
+    dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), groups);
+    if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float>), grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float>), grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16>), grid, dim3(256), 0, st, a);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal: convert up to 8 fp32 weight matrices to T (plain + transposed copies) in one launch.
+int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
+                        hipStream_t st) {
+    if (count < 1 || count > 8) return HYB_E_ARG;
+    ConvertArgs a{};
+    int maxN = 0, maxK = 0;
+    for (int i = 0; i < count; ++i) {
+        a.W[i] = W[i]; a.Wc[i] = Wc[i]; a.Wt[i] = Wt[i]; a.N[i] = N[i]; a.K[i] = K[i];
+        if (N[i] > maxN) maxN = N[i];
+        if (K[i] > maxK) maxK = K[i];
+    }
+    dim3 grid(hyb_cdiv(maxK, 32), hyb_cdiv(maxN, 32), count);
+    if (dtype == HYB_F32) hipLaunchKernelGGL(convert_weights_kernel<float>, grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(convert_weights_kernel<bf16>, grid, dim3(256), 0, st, a);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal: dym = dy * (y > 0) and db[n] = sum_m dym[m][n] helpers for the encoder backward
+int hyb_relu_mask(int dtype, const void* dy, const void* y, void* out, long long n, hipStream_t st) {
+    const long long n8 = n / 8;
+    int blocks = hyb_cdiv(n8, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == HYB_F32) hipLaunchKernelGGL(relu_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)out, n8);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(relu_mask_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)out, n8);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
 
 // Internal (same shared object): grouped forward used by the encoder to run Q, K, V in one launch.
 int hyb_linear_fwd_grouped3(int dtype, const void* const* x, const float* const* W, const float* const* b, void* const* y, int groups,
@@ -229,7 +395,7 @@ extern "C" int hyb_linear_bwd(int dtype, const void* x, int ldx, const float* W,
     HYB_CHECK_ARG(W && dy && M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldx >= K);
     HYB_CHECK_ARG(!dW || x);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return linear_bwd_t<float>(x, ldx, W, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
-    if (dtype == HYB_BF16) return linear_bwd_t<bf16>(x, ldx, W, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
+    if (dtype == HYB_F32) return linear_bwd_t<float>(x, ldx, W, nullptr, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
+    if (dtype == HYB_BF16) return linear_bwd_t<bf16>(x, ldx, W, nullptr, y, dy, dx, accumulate_dx, dW, db, M, N, K, relu, workspace, workspace_bytes, st);
     return HYB_E_ARG;
 }

@@ -5,8 +5,20 @@
 #include <math.h>
 #include "hyb_common.h"
 
-int hyb_linear_fwd_grouped3(int dtype, const void* const* x, const float* const* W, const float* const* b, void* const* y, int groups,
-                            int M, int N, int K, int relu, hipStream_t st);
+int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st);
+int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K, hipStream_t st);
+int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
+                      float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
+
+size_t hyb_stage1_fwd_workspace(int dtype, int Cop);
+size_t hyb_stage1_bwd_workspace(int dtype, int Cop);
+int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
+                   void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st);
+int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
+                   const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
+                   float* dbeta, void* workspace, hipStream_t st);
 
 namespace {
 
@@ -17,6 +29,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct EncLayout {       // byte offsets inside `saved` for one layer, plus per-layer stride
     size_t x_in, q, k, v, probs, attn, o, st1, x1, hmid, f, st2, layer_bytes;
+    size_t wc[6], wt[6];   // T copies (plain / transposed) of Wq, Wk, Wv, Wo, W1, W2, converted once per forward
 };
 inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -36,6 +49,8 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     L.hmid = take(M * Hid * es);
     L.f = take(M * D * es);
     L.st2 = take(2 * M * 4);
+    const size_t wsz[6] = {(size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)Hid * D, (size_t)D * Hid};
+    for (int i = 0; i < 6; ++i) { L.wc[i] = take(wsz[i] * es); L.wt[i] = take(wsz[i] * es); }
     L.layer_bytes = off;
     return L;
 }
@@ -49,6 +64,7 @@ inline unsigned long long drop_seed(unsigned long long seed, int layer) { return
 // conv stage
 // ----------------------------------------------------------------------------------------------------------
 extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop) {
+    if (first) return hyb_stage1_fwd_workspace(dtype, Cop);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     return align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es) + align256(2 * (size_t)Cop * 4) + align256(hyb_conv_stats_workspace(Cop));
 }
@@ -57,10 +73,13 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
                                  float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                                  int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
                                  float* mean_invstd, void* workspace, size_t workspace_bytes, void* stream) {
-    HYB_CHECK_ARG(x && weight && gamma && beta && running_mean && running_var && y_raw && pooled && scale_shift && mean_invstd && workspace);
+    HYB_CHECK_ARG(x && weight && gamma && beta && running_mean && running_var && (first || y_raw) && pooled && scale_shift && mean_invstd && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
-    HYB_CHECK_ARG(H >= 2 && W >= 2);
+    HYB_CHECK_ARG(H >= 2 && W >= 2 && Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0);
     if (workspace_bytes < hyb_convstage_fwd_workspace(dtype, first, Cip, Cop)) return HYB_E_WORKSPACE;
+    if (first)      // stage 1: the raw conv output is never materialised (recomputed in backward), y_raw is ignored
+        return hyb_stage1_fwd(dtype, (const float*)x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci,
+                              Co, Cop, pooled, scale_shift, mean_invstd, workspace, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     void* wp = ws;
@@ -75,6 +94,7 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
 }
 
 extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop) {
+    if (first) return hyb_stage1_bwd_workspace(dtype, Cop);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     size_t b = align256(2 * (size_t)Cop * 4);                                     // sums
     b += align256((size_t)N * H * W * Cop * es);                                  // dense grad of the raw conv output
@@ -87,10 +107,14 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
                                  const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
                                  int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    HYB_CHECK_ARG(dpooled && x && y_raw && weight && gamma && scale_shift && mean_invstd && dweight && workspace);
+    HYB_CHECK_ARG(dpooled && x && (first || y_raw) && weight && gamma && scale_shift && mean_invstd && dweight && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(first || dx);
+    HYB_CHECK_ARG(Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0 && H >= 2 && W >= 2);
     if (workspace_bytes < hyb_convstage_bwd_workspace(dtype, first, N, H, W, Cip, Cop)) return HYB_E_WORKSPACE;
+    if (first)
+        return hyb_stage1_bwd(dtype, dpooled, (const float*)x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight,
+                              dgamma, dbeta, workspace, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     float* sums = (float*)ws;                    ws += align256(2 * (size_t)Cop * 4);
@@ -144,18 +168,28 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
         const float* const* P = params + (size_t)i * 14;
         void* x_in = base + lay.x_in;
         void* y_out = (i == L - 1) ? out : (void*)(base + lay.layer_bytes + lay.x_in);
+        {   // fp32 master weights -> T copies (plain for forward, transposed for dX), one launch per layer
+            const float* Wsrc[6] = {P[0], P[2], P[4], P[6], P[8], P[10]};
+            void* Wc[6]; void* Wt[6];
+            for (int j = 0; j < 6; ++j) { Wc[j] = base + lay.wc[j]; Wt[j] = base + lay.wt[j]; }
+            const int Ns[6] = {D, D, D, D, Hid, D}, Ks[6] = {D, D, D, D, D, Hid};
+            HYB_TRY(hyb_convert_weights(dtype, 6, Wsrc, Wc, Wt, Ns, Ks, st));
+        }
         const void* xs[3] = {x_in, x_in, x_in};
-        const float* Ws[3] = {P[0], P[2], P[4]};
+        const void* Wq3[3] = {base + lay.wc[0], base + lay.wc[1], base + lay.wc[2]};
         const float* bs[3] = {P[1], P[3], P[5]};
         void* ys[3] = {base + lay.q, base + lay.k, base + lay.v};
-        HYB_TRY(hyb_linear_fwd_grouped3(dtype, xs, Ws, bs, ys, 3, M, D, D, 1, st));                                   // src L69-70
+        HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, D, 1, 0, st));                               // src L69-70
         HYB_TRY(hyb_attention_fwd(dtype, base + lay.q, base + lay.k, base + lay.v, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D,
                                   H, attn_p, attn_seed(seed, i), stream));                                            // src L73-84
-        HYB_TRY(hyb_linear_fwd(dtype, base + lay.attn, D, P[6], P[7], base + lay.o, M, D, D, 0, stream));             // src L87
+        { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, D, D, D, D, 0, 0, st)); }                            // src L87
         HYB_TRY(hyb_ln_residual_fwd(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
                                     0ull, stream));                                                                   // src L116-117
-        HYB_TRY(hyb_linear_fwd(dtype, base + lay.x1, D, P[8], P[9], base + lay.hmid, M, Hid, D, 1, stream));          // src L119 (Linear, ReLU)
-        HYB_TRY(hyb_linear_fwd(dtype, base + lay.hmid, Hid, P[10], P[11], base + lay.f, M, D, Hid, 0, stream));       // src L119 (Linear)
+        { const void* A_[1] = {base + lay.x1}; const void* B_[1] = {base + lay.wc[4]}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st)); }                        // src L119 (Linear, ReLU)
+        { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {base + lay.wc[5]}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, Hid, Hid, Hid, D, 0, 0, st)); }                      // src L119 (Linear)
         HYB_TRY(hyb_ln_residual_fwd(dtype, base + lay.f, base + lay.x1, P[12], P[13], y_out, (float*)(base + lay.st2), M, D, 1e-5f,
                                     (float)sqrt(0.5), layer_p, drop_seed(seed, i), stream));                          // src L120-123
     }
@@ -200,20 +234,20 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         HYB_TRY(hyb_ln_residual_bwd(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, G[12], G[13], M, D,
                                     (float)sqrt(0.5), layer_p, drop_seed(seed, i), stream));
         // FFN
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.hmid, Hid, P[10], nullptr, g1, dh, 0, G[10], G[11], M, D, Hid, 0, nullptr, 0, stream));
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.x1, D, P[8], base + lay.hmid, dh, g2, 1, G[8], G[9], M, Hid, D, 1, scratch, scratch_bytes, stream));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.hmid, Hid, P[10], base + lay.wt[5], nullptr, g1, dh, 0, G[10], G[11], M, D, Hid, 0, nullptr, 0, st));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x1, D, P[8], base + lay.wt[4], base + lay.hmid, dh, g2, 1, G[8], G[9], M, Hid, D, 1, scratch, scratch_bytes, st));
         // LN1 + residual
         HYB_TRY(hyb_ln_residual_bwd(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1, gx, 0, G[12], G[13], M, D, 1.0f, 0.f,
                                     0ull, stream));
         // output projection
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.attn, D, P[6], nullptr, g1, g4, 0, G[6], G[7], M, D, D, 0, nullptr, 0, stream));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.attn, D, P[6], base + lay.wt[3], nullptr, g1, g4, 0, G[6], G[7], M, D, D, 0, nullptr, 0, st));
         // attention core
         HYB_TRY(hyb_attention_bwd(dtype, base + lay.q, base + lay.k, base + lay.v, (const float*)(base + lay.probs), g4, g5, g6, g7, B, S, D, H,
                                   attn_p, attn_seed(seed, i), stream));
         // Q, K, V projections (ReLU), all three feed from the layer input
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.x_in, D, P[0], base + lay.q, g5, gx, 1, G[0], G[1], M, D, D, 1, scratch, scratch_bytes, stream));
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.x_in, D, P[2], base + lay.k, g6, gx, 1, G[2], G[3], M, D, D, 1, scratch, scratch_bytes, stream));
-        HYB_TRY(hyb_linear_bwd(dtype, base + lay.x_in, D, P[4], base + lay.v, g7, gx, 1, G[4], G[5], M, D, D, 1, scratch, scratch_bytes, stream));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[0], base + lay.wt[0], base + lay.q, g5, gx, 1, G[0], G[1], M, D, D, 1, scratch, scratch_bytes, st));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[2], base + lay.wt[1], base + lay.k, g6, gx, 1, G[2], G[3], M, D, D, 1, scratch, scratch_bytes, st));
+        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[4], base + lay.wt[2], base + lay.v, g7, gx, 1, G[4], G[5], M, D, D, 1, scratch, scratch_bytes, st));
         gA = gx;
     }
     return 0;

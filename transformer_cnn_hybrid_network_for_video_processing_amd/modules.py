@@ -61,7 +61,7 @@ class ConvBNReLUPool(nn.Sequential, _ComputeDtypeMixin):
         """Standalone use: [N,C,H,W] fp32 in, [N,features,H/2,W/2] fp32 out."""
         if x.dim() != 4:
             raise ValueError("expected [N,C,H,W]")
-        if self.in_channels <= 3:
+        if self.in_channels <= 4:
             h = self.forward_nhwc(x.float(), True)
         else:
             h = self.forward_nhwc(ops.nchw_to_nhwc(x, self._dt, ops.pad_channels(self.in_channels)), False)
@@ -172,7 +172,7 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
                                "(there is no CPU fallback)")
         B, T = x.shape[:2]
         f = x.reshape(B * T, *x.shape[2:]).float()                  # frames folded into the batch axis
-        if self.in_channels <= 3:
+        if self.in_channels <= 4:
             h = self.encoder1.forward_nhwc(f, True)
         else:
             h = self.encoder1.forward_nhwc(ops.nchw_to_nhwc(f, self._dt, ops.pad_channels(self.in_channels)), False)

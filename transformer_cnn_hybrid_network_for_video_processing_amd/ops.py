@@ -141,13 +141,16 @@ class ConvStageFn(torch.autograd.Function):
         if first:
             N, _, H, W = x.shape
             Cip = 0
+            if Ci > 4:
+                raise RuntimeError('first-stage kernel supports in_channels <= 4')
         else:
             N, H, W, Cip = x.shape
         if H < 2 or W < 2:
             raise RuntimeError(f"conv stage needs H, W >= 2 (got {H}x{W})")
         dev = x.device
         tdt = _TORCH_DTYPE[dt]
-        y_raw = torch.empty(N, H, W, Cop, dtype=tdt, device=dev)
+        # stage 1 recomputes its conv in backward: no full-resolution buffer is kept
+        y_raw = torch.empty(8, dtype=tdt, device=dev) if first else torch.empty(N, H, W, Cop, dtype=tdt, device=dev)
         pooled = torch.empty(N, H // 2, W // 2, Cop, dtype=tdt, device=dev)
         scale_shift = torch.empty(2, Cop, dtype=torch.float32, device=dev)
         mean_invstd = torch.empty(2, Cop, dtype=torch.float32, device=dev)
