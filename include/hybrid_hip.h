@@ -93,12 +93,15 @@ int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, voi
                          int N, int H, int W, int Cop, void* stream);
 
 /* backward of pool+relu+BN, two passes:
- *  reduce: sums[2][Cop] += (sum dy, sum dy*xhat) with dy routed through pool argmax and relu
+ *  reduce: sums[2][Cop] = (sum dy, sum dy*xhat) with dy routed through pool argmax and relu (overwritten; per-block
+ *          partial rows summed in a fixed order: reproducible, no float atomics)
  *  dx    : dyraw[N,H,W,Cop] = gamma*invstd*(dy - sum_dy/count - xhat*sum_dyxhat/count) (training)
  *                             gamma*invstd*dy                                        (eval)
  *          and writes dgamma[Co] = sum dy*xhat, dbeta[Co] = sum dy. */
+size_t hyb_bn_bwd_reduce_workspace(int Cop);
 int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* scale_shift,
-                                const float* mean_invstd, float* sums, int N, int H, int W, int Cop, void* stream);
+                                const float* mean_invstd, float* sums, float* partials /* hyb_bn_bwd_reduce_workspace bytes */,
+                                int N, int H, int W, int Cop, void* stream);
 int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const float* scale_shift,
                             const float* mean_invstd, const float* gamma, const float* sums, int training,
                             long long count, void* dyraw, float* dgamma, float* dbeta,

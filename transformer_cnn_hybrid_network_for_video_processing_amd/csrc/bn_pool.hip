@@ -48,28 +48,38 @@ __device__ __forceinline__ int argmax4(float v0, float v1, float v2, float v3, f
     return a;
 }
 
+// The three streaming kernels below walk pooled rows (n, ho): blockIdx strides over rows, threads over (wo, channel octet)
+// inside the row -- 32-bit index math only, and a thread keeps one channel octet for the whole kernel.
+__device__ __forceinline__ int row_threads(int oct) { return (256 / oct) * oct; }     // threads used per block (multiple of oct)
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ ss, T* __restrict__ out,
-                                                               int H, int W, int Cop, long long total) {
+                                                               int N, int H, int W, int Cop) {
     const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int oc = (int)(i % OCT);
-        const long long pix = i / OCT;
-        const int wo = (int)(pix % Wo);
-        const long long t2 = pix / Wo;
-        const int ho = (int)(t2 % Ho);
-        const long long n = t2 / Ho;
-        const T* src = y + (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
-        Vec8<T> a, b, c, d;
-        a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
-        Vec8<T> o;
+    const int nthr = row_threads(OCT);
+    if ((int)threadIdx.x >= nthr) return;
+    const int oc = threadIdx.x % OCT;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sc = ss[oc * 8 + j], sh = ss[Cop + oc * 8 + j];
-            float m = fmaxf(fmaxf(a.get(j) * sc + sh, b.get(j) * sc + sh), fmaxf(c.get(j) * sc + sh, d.get(j) * sc + sh));
-            o.set(j, fmaxf(m, 0.f));
+    for (int j = 0; j < 8; ++j) { sc[j] = ss[oc * 8 + j]; sh[j] = ss[Cop + oc * 8 + j]; }
+    const int rows = N * Ho, rowlen = Wo * OCT;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const T* yrow = y + ((long long)(n * H + 2 * ho) * W) * Cop;
+        T* orow = out + (long long)row * Wo * Cop;
+        for (int idx = threadIdx.x; idx < rowlen; idx += nthr) {
+            const int wo = idx / OCT;
+            const T* src = yrow + (long long)(2 * wo) * Cop + oc * 8;
+            Vec8<T> a, b, c, d, o;
+            a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float m = fmaxf(fmaxf(a.get(j) * sc[j] + sh[j], b.get(j) * sc[j] + sh[j]),
+                                      fmaxf(c.get(j) * sc[j] + sh[j], d.get(j) * sc[j] + sh[j]));
+                o.set(j, fmaxf(m, 0.f));
+            }
+            o.store(orow + (long long)wo * Cop + oc * 8);
         }
-        o.store(out + pix * Cop + oc * 8);
     }
 }
 
@@ -77,50 +87,53 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* __restrict__ dp, const T* __restrict__ y,
                                                                       const float* __restrict__ ss, const float* __restrict__ mi,
-                                                                      float* __restrict__ sums, int H, int W, int Cop, long long total) {
+                                                                      float* __restrict__ sums, int N, int H, int W, int Cop) {
     extern __shared__ float red[];                 // [2][Cop]
     const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
     for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
-    // the grid stride is a multiple of OCT, so a thread always owns the same 8 channels
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int oc = (int)(i0 % OCT);
-    float sc[8], sh[8], mean[8], inv[8], a1[8], a2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = ss[oc * 8 + j]; sh[j] = ss[Cop + oc * 8 + j];
-        mean[j] = mi[oc * 8 + j]; inv[j] = mi[Cop + oc * 8 + j];
-        a1[j] = 0.f; a2[j] = 0.f;
-    }
-    for (long long i = i0; i < total; i += stride) {
-        const long long pix = i / OCT;
-        const int wo = (int)(pix % Wo);
-        const long long t2 = pix / Wo;
-        const int ho = (int)(t2 % Ho);
-        const long long n = t2 / Ho;
-        const T* src = y + (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
-        Vec8<T> a, b, c, d, g;
-        a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
-        g.load(dp + pix * Cop + oc * 8);
+    const int nthr = row_threads(OCT);
+    if ((int)threadIdx.x < nthr) {
+        const int oc = threadIdx.x % OCT;
+        float sc[8], sh[8], mean[8], inv[8], a1[8], a2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
-            float vmax;
-            const int am = argmax4(y0 * sc[j] + sh[j], y1 * sc[j] + sh[j], y2 * sc[j] + sh[j], y3 * sc[j] + sh[j], vmax);
-            const float ysel = am == 0 ? y0 : am == 1 ? y1 : am == 2 ? y2 : y3;
-            const float dy = vmax > 0.f ? g.get(j) : 0.f;
-            a1[j] += dy;
-            a2[j] += dy * (ysel - mean[j]) * inv[j];
+            sc[j] = ss[oc * 8 + j]; sh[j] = ss[Cop + oc * 8 + j];
+            mean[j] = mi[oc * 8 + j]; inv[j] = mi[Cop + oc * 8 + j];
+            a1[j] = 0.f; a2[j] = 0.f;
+        }
+        const int rows = N * Ho, rowlen = Wo * OCT;
+        for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+            const int n = row / Ho, ho = row - n * Ho;
+            const T* yrow = y + ((long long)(n * H + 2 * ho) * W) * Cop;
+            const T* drow = dp + (long long)row * Wo * Cop;
+            for (int idx = threadIdx.x; idx < rowlen; idx += nthr) {
+                const int wo = idx / OCT;
+                const T* src = yrow + (long long)(2 * wo) * Cop + oc * 8;
+                Vec8<T> a, b, c, d, g;
+                a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
+                g.load(drow + (long long)wo * Cop + oc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
+                    float vmax;
+                    const int am = argmax4(y0 * sc[j] + sh[j], y1 * sc[j] + sh[j], y2 * sc[j] + sh[j], y3 * sc[j] + sh[j], vmax);
+                    const float ysel = am == 0 ? y0 : am == 1 ? y1 : am == 2 ? y2 : y3;
+                    const float dy = vmax > 0.f ? g.get(j) : 0.f;
+                    a1[j] += dy;
+                    a2[j] += dy * (ysel - mean[j]) * inv[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&red[oc * 8 + j], a1[j]);
+            atomicAdd(&red[Cop + oc * 8 + j], a2[j]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        atomicAdd(&red[oc * 8 + j], a1[j]);
-        atomicAdd(&red[Cop + oc * 8 + j], a2[j]);
-    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) atomicAdd(&sums[i], red[i]);
+    // one partial row per block: summed in a fixed order by the caller (no global float atomics)
+    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) sums[(long long)blockIdx.x * 2 * Cop + i] = red[i];
 }
 
 // pass 2: dense gradient w.r.t. the raw conv output.
@@ -129,75 +142,66 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_dx_kernel(const T* __res
                                                                   const float* __restrict__ ss, const float* __restrict__ mi,
                                                                   const float* __restrict__ gamma, const float* __restrict__ sums,
                                                                   int training, float inv_count, T* __restrict__ dyraw,
-                                                                  int H, int W, int Co, int Cop, long long total) {
+                                                                  int N, int H, int W, int Co, int Cop) {
     const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
     const bool oddW = (W & 1) != 0, oddH = (H & 1) != 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int oc = (int)(i % OCT);
-        const long long pix = i / OCT;
-        const int wo = (int)(pix % Wo);
-        const long long t2 = pix / Wo;
-        const int ho = (int)(t2 % Ho);
-        const long long n = t2 / Ho;
-        const long long base = (((n * H + 2 * ho) * W) + 2 * wo) * Cop + oc * 8;
-        Vec8<T> a, b, c, d, g;
-        a.load(y + base); b.load(y + base + Cop); c.load(y + base + (long long)W * Cop); d.load(y + base + (long long)W * Cop + Cop);
-        g.load(dp + pix * Cop + oc * 8);
-        Vec8<T> o0, o1, o2, o3;
+    const int nthr = row_threads(OCT);
+    if ((int)threadIdx.x >= nthr) return;
+    const int oc = threadIdx.x % OCT;
+    float sc[8], sh[8], mean[8], inv[8], kk[8], m1[8], m2[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ch = oc * 8 + j;
-            const float sc = ss[ch], sh = ss[Cop + ch], mean = mi[ch], inv = mi[Cop + ch];
-            const float gm = ch < Co ? gamma[ch] : 0.f;
-            const float k = gm * inv;
-            const float m1 = training ? sums[ch] * inv_count : 0.f;
-            const float m2 = training ? sums[Cop + ch] * inv_count : 0.f;
-            const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
-            float vmax;
-            const int am = argmax4(y0 * sc + sh, y1 * sc + sh, y2 * sc + sh, y3 * sc + sh, vmax);
-            const float dy = vmax > 0.f ? g.get(j) : 0.f;
-            o0.set(j, k * ((am == 0 ? dy : 0.f) - m1 - (y0 - mean) * inv * m2));
-            o1.set(j, k * ((am == 1 ? dy : 0.f) - m1 - (y1 - mean) * inv * m2));
-            o2.set(j, k * ((am == 2 ? dy : 0.f) - m1 - (y2 - mean) * inv * m2));
-            o3.set(j, k * ((am == 3 ? dy : 0.f) - m1 - (y3 - mean) * inv * m2));
-        }
-        o0.store(dyraw + base); o1.store(dyraw + base + Cop);
-        o2.store(dyraw + base + (long long)W * Cop); o3.store(dyraw + base + (long long)W * Cop + Cop);
-        // odd H/W: the last row/column is outside every pooling window (floor) but still carries the
-        // mean / xhat terms of the batch-norm gradient
-        if (oddW && wo == Wo - 1) {
+    for (int j = 0; j < 8; ++j) {
+        const int ch = oc * 8 + j;
+        sc[j] = ss[ch]; sh[j] = ss[Cop + ch]; mean[j] = mi[ch]; inv[j] = mi[Cop + ch];
+        kk[j] = (ch < Co ? gamma[ch] : 0.f) * inv[j];
+        m1[j] = training ? sums[ch] * inv_count : 0.f;
+        m2[j] = training ? sums[Cop + ch] * inv_count : 0.f;
+    }
+    auto dense_only = [&](long long off) {       // pixels outside every pooling window (odd H/W): dy = 0
+        Vec8<T> e, oe;
+        e.load(y + off);
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const long long bb = base + 2 * Cop + (long long)rr * W * Cop;
-                Vec8<T> e, oe;
-                e.load(y + bb);
+        for (int j = 0; j < 8; ++j) oe.set(j, kk[j] * (-m1[j] - (e.get(j) - mean[j]) * inv[j] * m2[j]));
+        oe.store(dyraw + off);
+    };
+    const int rows = N * Ho, rowlen = Wo * OCT;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / Ho, ho = row - n * Ho;
+        const long long rbase = ((long long)(n * H + 2 * ho) * W) * Cop;
+        const T* drow = dp + (long long)row * Wo * Cop;
+        for (int idx = threadIdx.x; idx < rowlen; idx += nthr) {
+            const int wo = idx / OCT;
+            const long long base = rbase + (long long)(2 * wo) * Cop + oc * 8;
+            Vec8<T> a, b, c, d, g;
+            a.load(y + base); b.load(y + base + Cop); c.load(y + base + (long long)W * Cop); d.load(y + base + (long long)W * Cop + Cop);
+            g.load(drow + (long long)wo * Cop + oc * 8);
+            Vec8<T> o0, o1, o2, o3;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ch = oc * 8 + j;
-                    const float k = (ch < Co ? gamma[ch] : 0.f) * mi[Cop + ch];
-                    const float m1 = training ? sums[ch] * inv_count : 0.f, m2 = training ? sums[Cop + ch] * inv_count : 0.f;
-                    oe.set(j, k * (-m1 - (e.get(j) - mi[ch]) * mi[Cop + ch] * m2));
-                }
-                oe.store(dyraw + bb);
+            for (int j = 0; j < 8; ++j) {
+                const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
+                float vmax;
+                const int am = argmax4(y0 * sc[j] + sh[j], y1 * sc[j] + sh[j], y2 * sc[j] + sh[j], y3 * sc[j] + sh[j], vmax);
+                const float dy = vmax > 0.f ? g.get(j) : 0.f;
+                o0.set(j, kk[j] * ((am == 0 ? dy : 0.f) - m1[j] - (y0 - mean[j]) * inv[j] * m2[j]));
+                o1.set(j, kk[j] * ((am == 1 ? dy : 0.f) - m1[j] - (y1 - mean[j]) * inv[j] * m2[j]));
+                o2.set(j, kk[j] * ((am == 2 ? dy : 0.f) - m1[j] - (y2 - mean[j]) * inv[j] * m2[j]));
+                o3.set(j, kk[j] * ((am == 3 ? dy : 0.f) - m1[j] - (y3 - mean[j]) * inv[j] * m2[j]));
             }
-        }
-        if (oddH && ho == Ho - 1) {
-            const int ncol = (oddW && wo == Wo - 1) ? 3 : 2;
-            for (int cc = 0; cc < ncol; ++cc) {
-                const long long bb = base + 2ll * W * Cop + (long long)cc * Cop;
-                Vec8<T> e, oe;
-                e.load(y + bb);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ch = oc * 8 + j;
-                    const float k = (ch < Co ? gamma[ch] : 0.f) * mi[Cop + ch];
-                    const float m1 = training ? sums[ch] * inv_count : 0.f, m2 = training ? sums[Cop + ch] * inv_count : 0.f;
-                    oe.set(j, k * (-m1 - (e.get(j) - mi[ch]) * mi[Cop + ch] * m2));
-                }
-                oe.store(dyraw + bb);
+            o0.store(dyraw + base); o1.store(dyraw + base + Cop);
+            o2.store(dyraw + base + (long long)W * Cop); o3.store(dyraw + base + (long long)W * Cop + Cop);
+            if (oddW && wo == Wo - 1) { dense_only(base + 2 * Cop); dense_only(base + 2 * Cop + (long long)W * Cop); }
+            if (oddH && ho == Ho - 1) {
+                dense_only(base + 2ll * W * Cop); dense_only(base + 2ll * W * Cop + Cop);
+                if (oddW && wo == Wo - 1) dense_only(base + 2ll * W * Cop + 2 * Cop);
             }
         }
     }
+}
+
+// sums[2][Cop] = sum over G partial rows (fixed order)
+__global__ __launch_bounds__(1024) void bn_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+    long long i; float v;
+    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
 }
 
 __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
@@ -288,6 +292,9 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict_
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) d[i] = from_f32<T>(s[i]);
 }
 
+constexpr int BN_MAX_ROWBLOCKS = 1024;
+inline int row_grid(int rows) { return rows < BN_MAX_ROWBLOCKS ? (rows < 1 ? 1 : rows) : BN_MAX_ROWBLOCKS; }
+
 inline int stream_grid(long long total, int cap = 4096) {
     long long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -317,30 +324,29 @@ extern "C" int hyb_bn_finalize(const float* stats, const float* gamma, const flo
 
 extern "C" int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* ss, void* pooled, int N, int H, int W, int Cop, void* stream) {
     HYB_CHECK_ARG(y && ss && pooled && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0);
-    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
+    HYB_CHECK_ARG(Cop / 8 <= 256);
+    const int grid = row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
     HYB_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, st, (const float*)y, ss, (float*)pooled, H, W, Cop, total),
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16>, dim3(stream_grid(total)), dim3(256), 0, st, (const bf16*)y, ss, (bf16*)pooled, H, W, Cop, total));
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, ss, (float*)pooled, N, H, W, Cop),
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, ss, (bf16*)pooled, N, H, W, Cop));
     HYB_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" size_t hyb_bn_bwd_reduce_workspace(int Cop) { return Cop > 0 ? (size_t)BN_MAX_ROWBLOCKS * 2 * Cop * sizeof(float) : 0; }
+
 extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* ss, const float* mi, float* sums,
-                                           int N, int H, int W, int Cop, void* stream) {
-    HYB_CHECK_ARG(dpooled && y && ss && mi && sums && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0);
-    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
-    const int oct = Cop / 8;
-    // grid*256 must be a multiple of oct so each thread keeps one channel octet: oct = 4*m, 256 = 4*64 => grid multiple of m/gcd(m,64)
-    int m = oct / 4, g = 64;
-    { int a = m, b = g; while (b) { int t = a % b; a = b; b = t; } m /= a; }
-    int grid = stream_grid(total, 2048);
-    grid = (grid + m - 1) / m * m;
+                                           float* partials, int N, int H, int W, int Cop, void* stream) {
+    HYB_CHECK_ARG(dpooled && y && ss && mi && sums && partials && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0 && Cop / 8 <= 256);
+    const int grid = row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)Cop * sizeof(float);
     HYB_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, sums, H, W, Cop, total),
-        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, sums, H, W, Cop, total));
+        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, partials, N, H, W, Cop),
+        hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, partials, N, H, W, Cop));
+    HYB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, partials, sums, grid, 2 * Cop);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -349,12 +355,13 @@ extern "C" int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const voi
                                        const float* sums, int training, long long count, void* dyraw, float* dgamma, float* dbeta,
                                        int N, int H, int W, int Co, int Cop, void* stream) {
     HYB_CHECK_ARG(dpooled && y && ss && mi && gamma && sums && dyraw && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Co <= Cop && count > 0);
-    const long long total = (long long)N * (H / 2) * (W / 2) * (Cop / 8);
+    HYB_CHECK_ARG(Cop / 8 <= 256);
+    const int grid = row_grid(N * (H / 2));
     const float inv_count = 1.0f / (float)count;
     hipStream_t st = (hipStream_t)stream;
     HYB_DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, st, (const float*)dpooled, (const float*)y, ss, mi, gamma, sums, training, inv_count, (float*)dyraw, H, W, Co, Cop, total),
-        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<bf16>, dim3(stream_grid(total)), dim3(256), 0, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, gamma, sums, training, inv_count, (bf16*)dyraw, H, W, Co, Cop, total));
+        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dpooled, (const float*)y, ss, mi, gamma, sums, training, inv_count, (float*)dyraw, N, H, W, Co, Cop),
+        hipLaunchKernelGGL(bn_relu_pool_bwd_dx_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, gamma, sums, training, inv_count, (bf16*)dyraw, N, H, W, Co, Cop));
     HYB_LAUNCH_CHECK();
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3(hyb_cdiv(Co, 256)), dim3(256), 0, st, sums, dgamma, dbeta, Co, Cop);

@@ -354,28 +354,14 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][co][tap*4 + ci]; fixed order (32 outputs x 8 slab groups per block)
-__global__ __launch_bounds__(256) void s1_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
-                                                              int Cop) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long long per = (long long)Cop * 48;
-    const long long i = (long long)blockIdx.x * 32 + col;
-    float a0 = 0.f, a1 = 0.f;
-    if (i < per) {
-        int k = grp;
-        for (; k + 8 < S; k += 16) { a0 += slab[(long long)k * per + i]; a1 += slab[(long long)(k + 8) * per + i]; }
-        if (k < S) a0 += slab[(long long)k * per + i];
-    }
-    red[grp][col] = a0 + a1;
-    __syncthreads();
-    if (grp != 0 || i >= per) return;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][col];
+// dw[co][ci][tap] = sum_s slab[s][co][tap*4 + ci]; fixed order
+__global__ __launch_bounds__(1024) void s1_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
+                                                               int Cop) {
+    long long i; float v;
+    if (!rows_reduce_1024(slab, S, (long long)Cop * 48, i, v)) return;
     const int kk = (int)(i % 48), co = (int)(i / 48);
     const int tap = kk >> 2, ci = kk & 3;
-    if (co < Co && tap < 9 && ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = s;
+    if (co < Co && tap < 9 && ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = v;
 }
 
 // packed first-layer weights for this path: T [Cop][64], k = tap*4 + c
@@ -390,25 +376,10 @@ __global__ void s1_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, 
     wp[i] = from_f32<T>(v);
 }
 
-// partial rows -> [n] (fixed order), shared with conv_fwd.hip's stats reduce in spirit
-__global__ __launch_bounds__(256) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
-    float a0 = 0.f, a1 = 0.f;
-    if (i < n) {
-        int g = grp;
-        for (; g + 8 < G; g += 16) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 8) * n + i]; }
-        if (g < G) a0 += part[(long long)g * n + i];
-    }
-    red[grp][col] = a0 + a1;
-    __syncthreads();
-    if (grp == 0 && i < n) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][col];
-        out[i] = s;
-    }
+// partial rows -> [n] (fixed order)
+__global__ __launch_bounds__(1024) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+    long long i; float v;
+    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
 }
 
 template <typename T, int NT, int MODE>
@@ -479,7 +450,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     if (training) {
         int rc = s1_dispatch<T, 0>(a, gx, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+        hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
         HYB_LAUNCH_CHECK();
     }
     int rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, (long long)N * H * W, Co, Cop,
@@ -511,11 +482,11 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const int gx = s1_grid(numTiles);
     int rc = s1_dispatch<T, 2>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, sums, gx, 2 * Cop);
+    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, sums, gx, 2 * Cop);
     HYB_LAUNCH_CHECK();
     rc = s1_dispatch<T, 3>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_wgrad_reduce_kernel, dim3(hyb_cdiv((long long)Cop * 48, 32)), dim3(256), 0, st, part, dweight, gx, Co, Ci, Cop);
+    hipLaunchKernelGGL(s1_wgrad_reduce_kernel, dim3(hyb_cdiv((long long)Cop * 48, 32)), dim3(1024), 0, st, part, dweight, gx, Co, Ci, Cop);
     HYB_LAUNCH_CHECK();
     if (dgamma || dbeta) {
         // dbeta = sum dy, dgamma = sum dy*xhat

@@ -360,25 +360,10 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __r
     wp[i] = from_f32<T>(v);
 }
 
-// stats[2][Cop] = sum over the G per-workgroup partial rows, fixed order: 32 columns x 8 row groups per block
-__global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restrict__ part, float* __restrict__ stats, int G, int n) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
-    float a0 = 0.f, a1 = 0.f;
-    if (i < n) {
-        int g = grp;
-        for (; g + 8 < G; g += 16) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 8) * n + i]; }
-        if (g < G) a0 += part[(long long)g * n + i];
-    }
-    red[grp][col] = a0 + a1;
-    __syncthreads();
-    if (grp == 0 && i < n) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][col];
-        stats[i] = s;
-    }
+// stats[2][Cop] = sum over the G per-workgroup partial rows, fixed order
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(const float* __restrict__ part, float* __restrict__ stats, int G, int n) {
+    long long i; float v;
+    if (rows_reduce_1024(part, G, n, i, v)) stats[i] = v;
 }
 
 constexpr int MAX_STAT_PARTIALS = 512;
@@ -402,7 +387,7 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
         HYB_LAUNCH_CHECK();
-        hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+        hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
     } else {
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
@@ -445,7 +430,7 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
 #undef HYB_FIRST
         HYB_LAUNCH_CHECK();
         if (stats) {
-            hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(256), 0, st, part, stats, gx, 2 * Cop);
+            hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
             HYB_LAUNCH_CHECK();
         }
         return 0;

@@ -175,24 +175,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_first_kernel(const float* _
 }
 
 // dw[co][ci][tap] = sum_s slab[s][co][tap][ci]  (first: slab[s][co][k], k = tap*Ci + ci); fixed summation order.
-// 32 outputs x 8 slab groups per block, LDS combine.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int first, int Co,
-                                                           int Ci, int Cop, int Cip, long long per_slab) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long long i = (long long)blockIdx.x * 32 + col;
-    float a0 = 0.f, a1 = 0.f;
-    if (i < per_slab) {
-        int k = grp;
-        for (; k + 8 < S; k += 16) { a0 += slab[(long long)k * per_slab + i]; a1 += slab[(long long)(k + 8) * per_slab + i]; }
-        if (k < S) a0 += slab[(long long)k * per_slab + i];
-    }
-    red[grp][col] = a0 + a1;
-    __syncthreads();
-    if (grp != 0 || i >= per_slab) return;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][col];
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int first, int Co,
+                                                            int Ci, int Cop, int Cip, long long per_slab) {
+    long long i; float s;
+    if (!rows_reduce_1024(slab, S, per_slab, i, s)) return;
     int co, ci, tap;
     if (first) {
         const int kk = (int)(i % 32);
@@ -244,7 +230,7 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
                            tilesY, numTiles);
     }
     HYB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(256), 0, st, slab, dw, p.S, first, Co, Ci, Cop, Cip, p.per_slab);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(1024), 0, st, slab, dw, p.S, first, Co, Ci, Cop, Cip, p.per_slab);
     HYB_LAUNCH_CHECK();
     return 0;
 }

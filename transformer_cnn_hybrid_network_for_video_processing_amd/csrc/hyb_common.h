@@ -128,3 +128,28 @@ __device__ __forceinline__ float dropout_mult(unsigned long long seed, unsigned 
     const float u = (float)(hyb_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
     return u >= p ? inv_keep : 0.0f;
 }
+
+// ---------------------------------------------------------------------------------------
+// Fixed-order sum of G partial rows of n floats: column i = sum_g part[g*n + i].  Launch with 1024 threads per block
+// (32 columns x 32 row groups), grid = ceil(n / 32).  Deterministic: no float atomics.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rows_reduce_1024(const float* __restrict__ part, int G, long long n, long long& col_out, float& sum_out) {
+    __shared__ float rr_red[32][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int g = grp;
+        for (; g + 32 < G; g += 64) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 32) * n + i]; }
+        if (g < G) a0 += part[(long long)g * n + i];
+    }
+    rr_red[grp][col] = a0 + a1;
+    __syncthreads();
+    if (grp != 0 || i >= n) return false;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += rr_red[k][col];
+    col_out = i;
+    sum_out = s;
+    return true;
+}

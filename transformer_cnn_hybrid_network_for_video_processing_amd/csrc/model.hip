@@ -96,7 +96,7 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
 extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop) {
     if (first) return hyb_stage1_bwd_workspace(dtype, Cop);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    size_t b = align256(2 * (size_t)Cop * 4);                                     // sums
+    size_t b = align256(2 * (size_t)Cop * 4) + align256(hyb_bn_bwd_reduce_workspace(Cop));   // sums + partial rows
     b += align256((size_t)N * H * W * Cop * es);                                  // dense grad of the raw conv output
     if (!first) b += align256((size_t)Cip * 9 * Cop * es);                        // dgrad-packed weights
     b += align256(hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop));         // wgrad slabs
@@ -118,14 +118,14 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     float* sums = (float*)ws;                    ws += align256(2 * (size_t)Cop * 4);
+    float* sum_part = (float*)ws;                ws += align256(hyb_bn_bwd_reduce_workspace(Cop));
     void* dyraw = ws;                            ws += align256((size_t)N * H * W * Cop * es);
     void* wpd = nullptr;
     if (!first) { wpd = ws;                      ws += align256((size_t)Cip * 9 * Cop * es); }
     void* slabs = ws;
     const size_t slab_bytes = hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop);
     const long long count = (long long)N * H * W;
-    HYB_HIP_TRY(hipMemsetAsync(sums, 0, 2 * (size_t)Cop * 4, (hipStream_t)stream));
-    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, N, H, W, Cop, stream));
+    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, sum_part, N, H, W, Cop, stream));
     HYB_TRY(hyb_bn_relu_pool_bwd_dx(dtype, dpooled, y_raw, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dgamma, dbeta, N, H,
                                     W, Co, Cop, stream));
     HYB_TRY(hyb_conv3x3_wgrad(dtype, first, x, dyraw, dweight, N, H, W, Ci, Cip, Co, Cop, slabs, slab_bytes, stream));
