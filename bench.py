@@ -155,12 +155,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("HYB_SINGLE_DEVICE"):       # test hook: several ranks share cuda:0 (one-GPU box, gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("HYB_DIST_BACKEND", "nccl")      # "nccl" is RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import transformer_cnn_hybrid_network_for_video_processing_amd as P
     from transformer_cnn_hybrid_network_for_video_processing_amd.dp import GradAllReducer

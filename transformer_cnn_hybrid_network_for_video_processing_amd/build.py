@@ -31,7 +31,7 @@ def build(force=False, verbose=False, jobs=4):
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-             "-Wno-unused-result"]
+             "-Wno-unused-result"] + os.environ.get("HYB_EXTRA_FLAGS", "").split()
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

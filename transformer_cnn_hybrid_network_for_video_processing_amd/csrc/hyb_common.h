@@ -71,6 +71,9 @@ template <> struct Vec8<bf16> {
     bf16x8 v;
     __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
     __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    // streaming (non-temporal) forms: touched once, should not displace L2-resident weights
+    __device__ __forceinline__ void load_nt(const bf16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+    __device__ __forceinline__ void store_nt(bf16* p) const { __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p)); }
     __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
     __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16)x; }
     __device__ __forceinline__ void zero() {
@@ -82,6 +85,12 @@ template <> struct Vec8<float> {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+    __device__ __forceinline__ void load_nt(const float* p) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    }
+    __device__ __forceinline__ void store_nt(float* p) const {
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+    }
     __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
     __device__ __forceinline__ void set(int j, float x) { if (j < 4) a[j] = x; else b[j - 4] = x; }
     __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = f32x4{0, 0, 0, 0}; }
