@@ -46,62 +46,139 @@ def parse():
 
 
 def conv_kernel_table(args, dt_code, tdt, dev):
-    """Time every conv GEMM kernel of one step standalone through the C ABI (HIP events on the launch stream)."""
+    """Time the contraction kernels of one step standalone through the C ABI (HIP events on the launch stream = torch's
+    current stream).  Rows with calls/step > 0 and composite=False are single kernels whose name appears in rocprof."""
     from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib
     st = torch.cuda.current_stream().cuda_stream
     es = 2 if tdt == torch.bfloat16 else 4
     N = args.batch * args.frames
     chans = (3,) + CFG["cnn_channels"]
     rows = []
+
+    def timeit(fn, reps=10):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     H = args.size
     for li in range(4):
         ci, co = chans[li], chans[li + 1]
-        first = li == 0
-        cip, cop = (0 if first else ci), co
-        x = torch.rand(N, ci, H, H, device=dev) if first else torch.rand(N, H, H, ci, device=dev).to(tdt)
+        flops = 2.0 * 9 * ci * co * H * H * N
+        if li == 0:
+            # stage 1 is a fused recompute path: time the whole stage (composite rows, several kernels each)
+            x = torch.rand(N, ci, H, H, device=dev)
+            w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+            gamma, beta = torch.ones(co, device=dev), torch.zeros(co, device=dev)
+            rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+            nbt = torch.zeros((), dtype=torch.int64, device=dev)
+            pooled = torch.empty(N, H // 2, H // 2, co, dtype=tdt, device=dev)
+            ss, mi = torch.empty(2, co, device=dev), torch.empty(2, co, device=dev)
+            wsf = torch.empty(lib.query("hyb_convstage_fwd_workspace", dt_code, 1, 0, co), dtype=torch.uint8, device=dev)
+            wsb = torch.empty(lib.query("hyb_convstage_bwd_workspace", dt_code, 1, N, H, H, 0, co), dtype=torch.uint8, device=dev)
+            dp = (torch.randn(N, H // 2, H // 2, co, device=dev) * 0.1).to(tdt)
+            dw, dg, db = torch.empty_like(w), torch.empty(co, device=dev), torch.empty(co, device=dev)
+
+            def s1f():
+                lib.call("hyb_convstage_fwd", dt_code, 1, x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                         nbt.data_ptr(), 1, 0.1, 1e-5, N, H, H, ci, 0, co, co, None, pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(),
+                         wsf.data_ptr(), wsf.numel(), st)
+
+            def s1b():
+                lib.call("hyb_convstage_bwd", dt_code, 1, dp.data_ptr(), x.data_ptr(), None, w.data_ptr(), gamma.data_ptr(), ss.data_ptr(), mi.data_ptr(),
+                         1, N, H, H, ci, 0, co, co, None, dw.data_ptr(), dg.data_ptr(), db.data_ptr(), wsb.data_ptr(), wsb.numel(), st)
+            rows.append(dict(kernel="stage1_fwd (conv+stats, conv+bn+relu+pool)", composite=True, flops=2 * flops,
+                             bytes=float(2 * N * ci * H * H * 4 + N * (H // 2) ** 2 * co * es), ms=timeit(s1f)))
+            rows.append(dict(kernel="stage1_bwd (recompute+reduce, recompute+wgrad)", composite=True, flops=3 * flops,
+                             bytes=float(2 * N * ci * H * H * 4 + 2 * N * (H // 2) ** 2 * co * es), ms=timeit(s1b)))
+            del x, pooled, dp, wsf, wsb
+            H //= 2
+            continue
+        cip, cop = ci, co
+        x = torch.rand(N, H, H, ci, device=dev).to(tdt)
         w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
-        wp = torch.empty(lib.query("hyb_conv_packed_elems", int(first), cip, cop), dtype=tdt, device=dev)
-        lib.call("hyb_conv_pack_weight", dt_code, 2 if first else 0, w.data_ptr(), wp.data_ptr(), co, ci, cop, cip, st)
+        wp = torch.empty(lib.query("hyb_conv_packed_elems", 0, cip, cop), dtype=tdt, device=dev)
+        lib.call("hyb_conv_pack_weight", dt_code, 0, w.data_ptr(), wp.data_ptr(), co, ci, cop, cip, st)
         y = torch.empty(N, H, H, cop, dtype=tdt, device=dev)
         stats = torch.zeros(2, cop, device=dev)
         part = torch.empty(lib.query("hyb_conv_stats_workspace", cop), dtype=torch.uint8, device=dev)
-        flops = 2.0 * 9 * ci * co * H * H * N
-
-        def t_fwd():
-            lib.call("hyb_conv3x3_fwd", dt_code, int(first), x.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), part.data_ptr(), N, H, H, ci, cip, cop, st)
-        rows.append(dict(kernel=f"conv{li + 1}_fwd", flops=flops, bytes=float(N * H * H * (ci * (4 if first else es) + co * es)), fn=t_fwd))
         dy = (torch.randn(N, H, H, cop, device=dev) * 0.1).to(tdt)
-        nb = lib.query("hyb_conv3x3_wgrad_workspace", int(first), N, H, H, cip, cop)
+        nb = lib.query("hyb_conv3x3_wgrad_workspace", 0, N, H, H, cip, cop)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        dw = torch.empty_like(w)
-
-        def t_wgrad():
-            lib.call("hyb_conv3x3_wgrad", dt_code, int(first), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, H, ci, cip, co, cop, ws.data_ptr(), nb, st)
-        rows.append(dict(kernel=f"conv{li + 1}_wgrad", flops=flops, bytes=float(N * H * H * (ci * (4 if first else es) + co * es)), fn=t_wgrad))
-        if not first:
-            wpd = torch.empty(cip * 9 * cop, dtype=tdt, device=dev)
-            lib.call("hyb_conv_pack_weight", dt_code, 1, w.data_ptr(), wpd.data_ptr(), co, ci, cop, cip, st)
-            dx = torch.empty(N, H, H, cip, dtype=tdt, device=dev)
-
-            def t_dgrad():
-                lib.call("hyb_conv3x3_fwd", dt_code, 0, dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, N, H, H, co, cop, cip, st)
-            rows.append(dict(kernel=f"conv{li + 1}_dgrad", flops=flops, bytes=float(N * H * H * (ci + co) * es), fn=t_dgrad))
-        for r in rows:
-            if "ms" in r:
-                continue
-            r["fn"](); r["fn"]()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
-            e0.record()
-            for _ in range(reps):
-                r["fn"]()
-            e1.record()
-            e1.synchronize()
-            r["ms"] = e0.elapsed_time(e1) / reps
-            del r["fn"]
-        del x, y, dy, ws
+        wpd = torch.empty(cip * 9 * cop, dtype=tdt, device=dev)
+        lib.call("hyb_conv_pack_weight", dt_code, 1, w.data_ptr(), wpd.data_ptr(), co, ci, cop, cip, st)
+        dx = torch.empty(N, H, H, cip, dtype=tdt, device=dev)
+        io_bytes = float(N * H * H * (ci + co) * es)
+        rows.append(dict(kernel=f"conv{li + 1}_fwd", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_nhwc_kernel",
+                         ms=timeit(lambda: lib.call("hyb_conv3x3_fwd", dt_code, 0, x.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                                    part.data_ptr(), N, H, H, ci, cip, cop, st))))
+        rows.append(dict(kernel=f"conv{li + 1}_dgrad", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_nhwc_kernel",
+                         ms=timeit(lambda: lib.call("hyb_conv3x3_fwd", dt_code, 0, dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None,
+                                                    N, H, H, co, cop, cip, st))))
+        # dw = NULL: only the contraction kernel (partial slabs), without the fixed-order slab reduce
+        rows.append(dict(kernel=f"conv{li + 1}_wgrad", composite=False, flops=flops, bytes=io_bytes,
+                         name="conv3x3_wgrad_kernel<%s>" % ("4" if cip % 64 == 0 else "2"),
+                         ms=timeit(lambda: lib.call("hyb_conv3x3_wgrad", dt_code, 0, x.data_ptr(), dy.data_ptr(), None, N, H, H, ci, cip, co, cop,
+                                                    ws.data_ptr(), nb, st))))
+        del x, y, dy, ws, dx
         H //= 2
     return rows
+
+
+def instep_kernel_table(args, step_fn, nsteps=8):
+    """Time the nine conv contraction kernels INSIDE real training steps: the library records HIP events on the launch
+    stream immediately around each hooked kernel (hyb_profile_set), one synchronised step at a time, outside the headline
+    timed region so the headline is not perturbed."""
+    from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib
+    N = args.batch * args.frames
+    chans = (3,) + CFG["cnn_channels"]
+    specs = []
+    H = args.size // 2
+    for li in range(1, 4):
+        ci, co = chans[li], chans[li + 1]
+        flops = 2.0 * 9 * ci * co * H * H * N
+        io = float(N * H * H * (ci + co) * 2)
+        specs.append((f"conv{li + 1}_fwd", 1, ci, co, "conv3x3_nhwc_kernel", flops, io))
+        specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_nhwc_kernel", flops, io))
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "conv3x3_wgrad_kernel<%s>" % ("4" if ci % 64 == 0 else "2"), flops, io))
+        H //= 2
+    evs = []
+    for slot, sp in enumerate(specs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()                       # force creation of the underlying hipEvent_t
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    for slot, sp in enumerate(specs):
+        lib.call("hyb_profile_set", slot, sp[1], sp[2], sp[3], evs[slot][0].cuda_event, evs[slot][1].cuda_event)
+    acc = [0.0] * len(specs)
+    try:
+        for _ in range(nsteps):
+            step_fn()
+            torch.cuda.synchronize()
+            for i, (e0, e1) in enumerate(evs):
+                acc[i] += e0.elapsed_time(e1)
+    finally:
+        lib.call("hyb_profile_clear")
+    return [dict(kernel=sp[0], composite=False, name=sp[4], flops=sp[5], bytes=sp[6], ms=acc[i] / nsteps) for i, sp in enumerate(specs)]
+
+
+def dominant_kernel(rows):
+    """The kernel NAME with the largest total time per step (what rocprofv3 --stats ranks first among the contractions)."""
+    tot = {}
+    for r in rows:
+        if r.get("composite"):
+            continue
+        key = r["name"] if r["name"].startswith("conv3x3_wgrad") else r["kernel"]      # fwd/dgrad instances differ per layer
+        tot.setdefault(key, []).append(r)
+    key = max(tot, key=lambda k: sum(r["ms"] for r in tot[k]))
+    grp = tot[key]
+    ms = sum(r["ms"] for r in grp) / len(grp)
+    return dict(name=key, launches_per_step=len(grp), layers=[r["kernel"] for r in grp], ms=ms, flops=grp[0]["flops"],
+                bytes=sum(r["bytes"] for r in grp) / len(grp))
 
 
 def host_cores():
@@ -237,13 +314,21 @@ def main():
         }
         if not args.no_roofline and world == 1:
             dt_code = ops.dtype_code(args.dtype)
-            rows = conv_kernel_table(args, dt_code, ops.torch_dtype(dt_code), dev)
-            dom = max(rows, key=lambda r: r["ms"])
+            rows = instep_kernel_table(args, step)
+            dom = dominant_kernel(rows)
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "ms": dom["ms"],
-                               "hbm_GBps_algorithmic": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")          # PMC bytes per launch (rocprofv3 --pmc)
+            if os.path.exists(tpath) and args.dtype == "bf16":
+                t = json.load(open(tpath)).get(dom["name"])
+                if t:
+                    traffic = t["hbm_bytes_per_launch"]
+            out["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "launches_per_step": dom["launches_per_step"],
+                               "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": traffic, "ms": dom["ms"], "flops_per_launch": dom["flops"],
+                               "algorithmic_bytes_per_launch": dom["bytes"],
+                               "how": "HIP events recorded by the library around this kernel inside 8 real steps (hyb_profile_set)"}
             out["kernel_table"] = [{"kernel": r["kernel"], "ms": round(r["ms"], 4), "TFLOPs": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                                     "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows]
         if not args.no_cpu_baseline and world == 1:

@@ -48,6 +48,16 @@ int hyb_dtype_size(int dtype);
 /* round a channel count up to the internal padded count */
 int hyb_pad_channels(int c);
 
+/* ---- measurement hook (bench.py): time ONE kernel launch inside a real step with HIP events -----------
+ * hyb_profile_set(slot, kernel_id, a, b, ev_start, ev_stop): the next launches of kernel `kernel_id` whose shape key is
+ * (a, b) record hipEvent_t ev_start / ev_stop on the launch stream immediately before / after that kernel only.
+ *   kernel_id 1: conv3x3_nhwc_kernel        (a = Cip, b = Cop as passed to hyb_conv3x3_fwd; forward and dgrad launches)
+ *   kernel_id 2: conv3x3_wgrad_kernel       (a = Cip, b = Cop)
+ * slot in [0, 16).  hyb_profile_clear() removes all hooks.  This is the only process-global state in the library; it is
+ * never touched unless a hook is set, and it is not thread-safe (measurement runs only). */
+int hyb_profile_set(int slot, int kernel_id, int a, int b, void* ev_start, void* ev_stop);
+int hyb_profile_clear(void);
+
 /* layout conversion helpers (used by tests and by in_channels > 3):
  * NCHW fp32 [N,C,H,W] <-> NHWC T [N,H,W,Cp] (padded channels written as zero). */
 int hyb_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, void* stream);
@@ -108,7 +118,8 @@ int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const
                             int N, int H, int W, int Co, int Cop, void* stream);
 
 /* weight gradient of the conv: dw fp32 [Co,Ci,3,3] = sum_{n,h,w} dy (x) patch(x).
- * x as in hyb_conv3x3_fwd (first selects NCHW fp32 input).  workspace: fp32 slabs. */
+ * x as in hyb_conv3x3_fwd (first selects NCHW fp32 input).  workspace: fp32 partial slabs, summed in a fixed order.
+ * dw == NULL leaves only the partial slabs in the workspace (skips the final reduce). */
 size_t hyb_conv3x3_wgrad_workspace(int first, int N, int H, int W, int Cip, int Cop);
 int hyb_conv3x3_wgrad(int dtype, int first, const void* x, const void* dy, float* dw,
                       int N, int H, int W, int Ci, int Cip, int Co, int Cop,

@@ -9,4 +9,5 @@ a = ap.parse_args()
 dt = ops.dtype_code(a.dtype)
 rows = bench.conv_kernel_table(a, dt, ops.torch_dtype(dt), torch.device("cuda", 0))
 for r in rows:
-    print("%-14s %8.4f ms  %8.1f TF/s  %8.1f GB/s" % (r["kernel"], r["ms"], r["flops"] / r["ms"] / 1e9, r["bytes"] / r["ms"] / 1e6))
+    print("%-50s %8.4f ms  %8.1f TF/s  %8.1f GB/s" % (r["kernel"], r["ms"], r["flops"] / r["ms"] / 1e9, r["bytes"] / r["ms"] / 1e6))
+print(bench.dominant_kernel(rows))

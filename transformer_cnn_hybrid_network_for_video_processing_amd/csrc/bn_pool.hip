@@ -307,6 +307,21 @@ inline int stream_grid(long long total, int cap = 4096) {
 #define HYB_DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
     do { if ((dtype) == HYB_F32) { CALL_F32; } else if ((dtype) == HYB_BF16) { CALL_BF16; } else return HYB_E_ARG; } while (0)
 
+HybProfileHook g_hyb_hooks[16];
+int g_hyb_hooks_active = 0;
+
+extern "C" int hyb_profile_set(int slot, int kernel_id, int a, int b, void* ev_start, void* ev_stop) {
+    HYB_CHECK_ARG(slot >= 0 && slot < 16 && ev_start && ev_stop && kernel_id > 0);
+    g_hyb_hooks[slot] = HybProfileHook{kernel_id, a, b, (hipEvent_t)ev_start, (hipEvent_t)ev_stop};
+    g_hyb_hooks_active = 1;
+    return 0;
+}
+extern "C" int hyb_profile_clear(void) {
+    for (int i = 0; i < 16; ++i) g_hyb_hooks[i] = HybProfileHook{0, 0, 0, nullptr, nullptr};
+    g_hyb_hooks_active = 0;
+    return 0;
+}
+
 extern "C" int hyb_abi_version(void) { return 1; }
 extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
 extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }

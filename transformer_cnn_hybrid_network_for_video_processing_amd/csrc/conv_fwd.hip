@@ -383,14 +383,18 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
+    HybProfileHook* hook = hyb_find_hook(1, Cip, Cop);
+    if (hook) hipEventRecord(hook->ev0, st);
     if (stats) {
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
+        if (hook) hipEventRecord(hook->ev1, st);
         HYB_LAUNCH_CHECK();
         hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
     } else {
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
+        if (hook) hipEventRecord(hook->ev1, st);
     }
     HYB_LAUNCH_CHECK();
     return 0;

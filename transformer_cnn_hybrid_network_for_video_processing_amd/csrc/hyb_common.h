@@ -18,6 +18,17 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 static inline int hyb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// measurement hooks (hyb_profile_set): defined in bn_pool.hip
+struct HybProfileHook { int kernel_id, a, b; hipEvent_t ev0, ev1; };
+extern HybProfileHook g_hyb_hooks[16];
+extern int g_hyb_hooks_active;
+static inline HybProfileHook* hyb_find_hook(int kernel_id, int a, int b) {
+    if (!g_hyb_hooks_active) return nullptr;
+    for (int i = 0; i < 16; ++i)
+        if (g_hyb_hooks[i].kernel_id == kernel_id && g_hyb_hooks[i].a == a && g_hyb_hooks[i].b == b) return &g_hyb_hooks[i];
+    return nullptr;
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
