@@ -86,11 +86,11 @@ def conv_kernel_table(args, dt_code, tdt, dev):
             def s1f():
                 lib.call("hyb_convstage_fwd", dt_code, 1, x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                          nbt.data_ptr(), 1, 0.1, 1e-5, N, H, H, ci, 0, co, co, None, pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(),
-                         wsf.data_ptr(), wsf.numel(), st)
+                         None, wsf.data_ptr(), wsf.numel(), st)
 
             def s1b():
                 lib.call("hyb_convstage_bwd", dt_code, 1, dp.data_ptr(), x.data_ptr(), None, w.data_ptr(), gamma.data_ptr(), ss.data_ptr(), mi.data_ptr(),
-                         1, N, H, H, ci, 0, co, co, None, dw.data_ptr(), dg.data_ptr(), db.data_ptr(), wsb.data_ptr(), wsb.numel(), st)
+                         1, N, H, H, ci, 0, co, co, None, dw.data_ptr(), dg.data_ptr(), db.data_ptr(), None, wsb.data_ptr(), wsb.numel(), st)
             rows.append(dict(kernel="stage1_fwd (conv+stats, conv+bn+relu+pool)", composite=True, flops=2 * flops,
                              bytes=float(2 * N * ci * H * H * 4 + N * (H // 2) ** 2 * co * es), ms=timeit(s1f)))
             rows.append(dict(kernel="stage1_bwd (recompute+reduce, recompute+wgrad)", composite=True, flops=3 * flops,
@@ -255,7 +255,10 @@ def main():
                                    dropout=0.0, compute_dtype=args.dtype).to(dev)
     model.train()
     crit = P.HybridCrossEntropyLoss()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)      # stock torch optimizer, single fused multi-tensor kernel
+    except Exception:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     reducer = GradAllReducer(model) if world > 1 else None
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)          # rank r seeds its own clips

@@ -86,6 +86,9 @@ int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, 
  *        (caller workspace of hyb_conv_stats_workspace(Cop) bytes) summed in a fixed order:
  *        bitwise reproducible, no float atomics. */
 size_t hyb_conv_stats_workspace(int Cop);
+/* number of partial rows hyb_conv3x3_fwd writes for this problem (stats == NULL with stats_partials != NULL leaves only
+ * the partial rows: feed them to hyb_bn_stats_finalize) */
+int hyb_conv_stats_rows(int first, int N, int H, int W, int Cop);
 int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, float* stats_partials,
                     int N, int H, int W, int Ci, int Cip, int Cop, void* stream);
 
@@ -97,6 +100,12 @@ int hyb_bn_finalize(const float* stats, const float* gamma, const float* beta, f
                     float* running_var, long long* num_batches_tracked, int training, float momentum,
                     float eps, long long count, int Co, int Cop, float* scale_shift, float* mean_invstd,
                     void* stream);
+
+/* training-mode shortcut: the same, computed straight from the G per-workgroup partial rows hyb_conv3x3_fwd left in
+ * `stats_partials` (fixed-order sum + finalize in one launch).  G = hyb_conv_stats_rows(...). */
+int hyb_bn_stats_finalize(const float* stats_partials, int G, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
+                          int Co, int Cop, float* scale_shift, float* mean_invstd, void* stream);
 
 /* pooled[N,H/2,W/2,Cop] = maxpool2x2(relu(y*scale+shift)) (floor; H,W >= 2) */
 int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, void* pooled,
@@ -111,7 +120,8 @@ int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, voi
 size_t hyb_bn_bwd_reduce_workspace(int Cop);
 int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* scale_shift,
                                 const float* mean_invstd, float* sums, float* partials /* hyb_bn_bwd_reduce_workspace bytes */,
-                                int N, int H, int W, int Cop, void* stream);
+                                float* dgamma /* [Co] or NULL */, float* dbeta /* [Co] or NULL */,
+                                int N, int H, int W, int Co, int Cop, void* stream);
 int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const float* scale_shift,
                             const float* mean_invstd, const float* gamma, const float* sums, int training,
                             long long count, void* dyraw, float* dgamma, float* dbeta,
@@ -133,13 +143,16 @@ int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, 
                       int N, int H, int W, int Ci, int Cip, int Co, int Cop,
                       void* y_raw /* [N,H,W,Cop] T, saved */, void* pooled /* [N,H/2,W/2,Cop] T */,
                       float* scale_shift /* [2][Cop] saved */, float* mean_invstd /* [2][Cop] saved */,
+                      void* packed_bwd /* NULL, or hyb_convstage_packed_bwd_elems() T elements: weights packed for backward, saved */,
                       void* workspace, size_t workspace_bytes, void* stream);
+long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop);
 size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop);
 int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw,
                       const float* weight, const float* gamma, const float* scale_shift,
                       const float* mean_invstd, int training,
                       int N, int H, int W, int Ci, int Cip, int Co, int Cop,
                       void* dx /* [N,H,W,Cip] T, NULL when first */, float* dweight, float* dgamma, float* dbeta,
+                      const void* packed_bwd /* from hyb_convstage_fwd, or NULL to repack */,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- frame token: global average pool over H*W (the composite's own glue) ----------- */

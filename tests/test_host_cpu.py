@@ -24,7 +24,7 @@ def built():
 
 def test_header_declares_expected_entry_points():
     protos = _lib.parse_header()
-    for name in ["hyb_conv3x3_fwd", "hyb_conv3x3_wgrad", "hyb_convstage_fwd", "hyb_convstage_bwd", "hyb_bn_finalize",
+    for name in ["hyb_conv3x3_fwd", "hyb_conv3x3_wgrad", "hyb_bn_stats_finalize", "hyb_profile_set", "hyb_convstage_fwd", "hyb_convstage_bwd", "hyb_bn_finalize",
                  "hyb_bn_relu_pool_fwd", "hyb_linear_fwd", "hyb_linear_bwd", "hyb_attention_fwd", "hyb_attention_bwd",
                  "hyb_ln_residual_fwd", "hyb_ln_residual_bwd", "hyb_encoder_fwd", "hyb_encoder_bwd", "hyb_head_fwd",
                  "hyb_head_bwd", "hyb_cross_entropy_fwd", "hyb_cross_entropy_bwd", "hyb_gap_fwd", "hyb_gap_bwd"]:

@@ -38,6 +38,36 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
     mean_invstd[Cop + c] = invstd;
 }
 
+// partial rows [G][2][Cop] -> statistics -> finalize, one launch (1024 threads: 32 channels x 32 row groups per block)
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int G, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, long long* __restrict__ nbt, float momentum,
+                                                                 float eps, long long count, int Co, int Cop, float* __restrict__ scale_shift,
+                                                                 float* __restrict__ mean_invstd) {
+    long long i1, i2; float s1 = 0.f, s2 = 0.f;
+    const bool ok1 = rows_reduce_1024(part, G, 2ll * Cop, i1, s1, 0, Cop);
+    const bool ok2 = rows_reduce_1024(part, G, 2ll * Cop, i2, s2, Cop, Cop);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    if (!(ok1 && ok2)) return;
+    const int c = (int)i1;
+    float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
+    if (c < Co) {
+        g = gamma[c]; b = beta[c];
+        const float inv_n = 1.0f / (float)count;
+        mean = s1 * inv_n;
+        float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+        invstd = rsqrtf(var + eps);
+        const float unbiased = count > 1 ? var * ((float)count / (float)(count - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    const float scale = g * invstd;
+    scale_shift[c] = scale;
+    scale_shift[Cop + c] = b - mean * scale;
+    mean_invstd[c] = mean;
+    mean_invstd[Cop + c] = invstd;
+}
+
 // first maximum of the four transformed values in torch's window scan order (0,0),(0,1),(1,0),(1,1)
 __device__ __forceinline__ int argmax4(float v0, float v1, float v2, float v3, float& vmax) {
     int a = 0;
@@ -198,10 +228,14 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_dx_kernel(const T* __res
     }
 }
 
-// sums[2][Cop] = sum over G partial rows (fixed order)
-__global__ __launch_bounds__(1024) void bn_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+// sums[2][Cop] = sum over G partial rows (fixed order); also dbeta[c] = sums[c], dgamma[c] = sums[Cop + c] for c < Co
+__global__ __launch_bounds__(1024) void bn_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
     long long i; float v;
-    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
+    if (!rows_reduce_1024(part, G, n, i, v)) return;
+    out[i] = v;
+    if (i < Cop) { if (dbeta && i < Co) dbeta[i] = v; }
+    else if (dgamma && i - Cop < Co) dgamma[i - Cop] = v;
 }
 
 __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
@@ -351,8 +385,18 @@ extern "C" int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* ss, v
 
 extern "C" size_t hyb_bn_bwd_reduce_workspace(int Cop) { return Cop > 0 ? (size_t)BN_MAX_ROWBLOCKS * 2 * Cop * sizeof(float) : 0; }
 
+extern "C" int hyb_bn_stats_finalize(const float* stats_partials, int G, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, long long* nbt, float momentum, float eps, long long count, int Co, int Cop,
+                                     float* scale_shift, float* mean_invstd, void* stream) {
+    HYB_CHECK_ARG(stats_partials && G > 0 && gamma && beta && running_mean && running_var && scale_shift && mean_invstd && Co > 0 && Cop >= Co && count > 0);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(hyb_cdiv(Cop, 32)), dim3(1024), 0, (hipStream_t)stream, stats_partials, G, gamma, beta,
+                       running_mean, running_var, nbt, momentum, eps, count, Co, Cop, scale_shift, mean_invstd);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* ss, const float* mi, float* sums,
-                                           float* partials, int N, int H, int W, int Cop, void* stream) {
+                                           float* partials, float* dgamma, float* dbeta, int N, int H, int W, int Co, int Cop, void* stream) {
     HYB_CHECK_ARG(dpooled && y && ss && mi && sums && partials && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0 && Cop / 8 <= 256);
     const int grid = row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
@@ -361,7 +405,7 @@ extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, partials, N, H, W, Cop),
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, partials, N, H, W, Cop));
     HYB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, partials, sums, grid, 2 * Cop);
+    hipLaunchKernelGGL(bn_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, partials, sums, grid, 2 * Cop, dgamma, dbeta, Co, Cop);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -376,10 +376,14 @@ __global__ void s1_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, 
     wp[i] = from_f32<T>(v);
 }
 
-// partial rows -> [n] (fixed order)
-__global__ __launch_bounds__(1024) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+// partial rows -> sums[2][Cop] (fixed order), plus dbeta / dgamma for c < Co
+__global__ __launch_bounds__(1024) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
     long long i; float v;
-    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
+    if (!rows_reduce_1024(part, G, n, i, v)) return;
+    out[i] = v;
+    if (i < Cop) { if (dbeta && i < Co) dbeta[i] = v; }
+    else if (dgamma && i - Cop < Co) dgamma[i - Cop] = v;
 }
 
 template <typename T, int NT, int MODE>
@@ -430,10 +434,10 @@ static int s1_grid(long long numTiles) {
 template <typename T>
 static int stage1_fwd_t(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co,
-                        int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st) {
+                        int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
-    T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
+    T* wp = packed_out ? (T*)packed_out : (T*)ws; ws += al256((size_t)Cop * 64 * es);      // packed weights are kept for backward when asked
     float* stats = (float*)ws;                   ws += al256(2 * (size_t)Cop * 4);
     float* part = (float*)ws;
     const long long total = (long long)Cop * 64;
@@ -447,14 +451,16 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
     const int gx = s1_grid(numTiles);
+    int rc;
     if (training) {
-        int rc = s1_dispatch<T, 0>(a, gx, st);
+        rc = s1_dispatch<T, 0>(a, gx, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
-        HYB_LAUNCH_CHECK();
-    }
-    int rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, (long long)N * H * W, Co, Cop,
+        rc = hyb_bn_stats_finalize(part, gx, gamma, beta, running_mean, running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop,
+                                   scale_shift, mean_invstd, (void*)st);
+    } else {
+        rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, 0, momentum, eps, (long long)N * H * W, Co, Cop,
                              scale_shift, mean_invstd, (void*)st);
+    }
     if (rc) return rc;
     return s1_dispatch<T, 1>(a, gx, st);
 }
@@ -462,15 +468,19 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
 template <typename T>
 static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                         const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                        float* dbeta, void* workspace, hipStream_t st) {
+                        float* dbeta, const void* packed_in, void* workspace, hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
     float* sums = (float*)ws;                    ws += al256(2 * (size_t)Cop * 4);
     float* part = (float*)ws;
-    const long long total = (long long)Cop * 64;
-    hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
-    HYB_LAUNCH_CHECK();
+    if (packed_in) {
+        wp = (T*)packed_in;                      // packed by the forward pass
+    } else {
+        const long long total = (long long)Cop * 64;
+        hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
+        HYB_LAUNCH_CHECK();
+    }
     S1Args a{};
     a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = sums; a.dp = dpooled; a.part = part;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
@@ -482,34 +492,29 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const int gx = s1_grid(numTiles);
     int rc = s1_dispatch<T, 2>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, sums, gx, 2 * Cop);
+    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, sums, gx, 2 * Cop, dgamma, dbeta, Co, Cop);
     HYB_LAUNCH_CHECK();
     rc = s1_dispatch<T, 3>(a, gx, st);
     if (rc) return rc;
     hipLaunchKernelGGL(s1_wgrad_reduce_kernel, dim3(hyb_cdiv((long long)Cop * 48, 32)), dim3(1024), 0, st, part, dweight, gx, Co, Ci, Cop);
     HYB_LAUNCH_CHECK();
-    if (dgamma || dbeta) {
-        // dbeta = sum dy, dgamma = sum dy*xhat
-        if (dbeta) { hipError_t e = hipMemcpyAsync(dbeta, sums, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
-        if (dgamma) { hipError_t e = hipMemcpyAsync(dgamma, sums + Cop, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
-    }
     return 0;
 }
 
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st) {
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, workspace, st);
-    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, workspace, st);
+    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, st);
+    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, st);
     return HYB_E_ARG;
 }
 
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                   float* dbeta, void* workspace, hipStream_t st) {
+                   float* dbeta, const void* packed_in, void* workspace, hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_bwd_t<float>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, workspace, st);
-    if (dtype == HYB_BF16) return stage1_bwd_t<bf16>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, workspace, st);
+    if (dtype == HYB_F32) return stage1_bwd_t<float>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, st);
+    if (dtype == HYB_BF16) return stage1_bwd_t<bf16>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, st);
     return HYB_E_ARG;
 }

@@ -379,18 +379,18 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
     if (lds > 64 * 1024) {
-        const void* f = stats ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>;
+        const void* f = part ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>;
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     HybProfileHook* hook = hyb_find_hook(1, Cip, Cop);
     if (hook) hipEventRecord(hook->ev0, st);
-    if (stats) {
+    if (part) {
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
         if (hook) hipEventRecord(hook->ev1, st);
         HYB_LAUNCH_CHECK();
-        hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
+        if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
     } else {
         hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
@@ -429,8 +429,8 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
             dim3 grid(gx, gy);
 #define HYB_FIRST(NT_, ST_) hipLaunchKernelGGL((conv3x3_first_kernel<T, NT_, ST_>), grid, dim3(256), 0, st, (const float*)x, (const T*)wp, \
                                                (T*)y, part, N, H, W, Ci, Cop, tilesX, tilesY, (int)numTiles)
-        if (nt == 4) { if (stats) HYB_FIRST(4, true); else HYB_FIRST(4, false); }
-        else         { if (stats) HYB_FIRST(2, true); else HYB_FIRST(2, false); }
+        if (nt == 4) { if (part) HYB_FIRST(4, true); else HYB_FIRST(4, false); }
+        else         { if (part) HYB_FIRST(2, true); else HYB_FIRST(2, false); }
 #undef HYB_FIRST
         HYB_LAUNCH_CHECK();
         if (stats) {
@@ -452,6 +452,41 @@ extern "C" long long hyb_conv_packed_elems(int first, int Cip, int Cop) {
     return first ? (long long)Cop * 32 : (long long)Cop * 9 * Cip;
 }
 
+// forward (mode 0) and dgrad (mode 1) layouts in ONE launch (internal; used by hyb_convstage_fwd)
+template <typename T>
+__global__ void pack_weight_dual_kernel(const float* __restrict__ w, T* __restrict__ wp0, T* __restrict__ wp1, int Co, int Ci, int Cop, int Cip,
+                                        long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * count) return;
+    const bool second = i >= count;
+    const long long k = second ? i - count : i;
+    const int c32 = (int)(k % 32);
+    const int tap = (int)((k / 32) % 9);
+    float v = 0.f;
+    if (!second) {
+        const int chunk = (int)((k / 288) % (Cip / 32));
+        const int co = (int)(k / ((long long)9 * Cip));
+        const int ci = chunk * 32 + c32;
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
+        wp0[k] = from_f32<T>(v);
+    } else {
+        const int chunk = (int)((k / 288) % (Cop / 32));
+        const int ci = (int)(k / ((long long)9 * Cop));
+        const int co = chunk * 32 + c32;
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
+        wp1[k] = from_f32<T>(v);
+    }
+}
+int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, int Co, int Ci, int Cop, int Cip, hipStream_t st) {
+    const long long count = (long long)Cop * 9 * Cip;
+    const int blocks = hyb_cdiv(2 * count, 256);
+    if (dtype == HYB_F32) hipLaunchKernelGGL(pack_weight_dual_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)wp0, (float*)wp1, Co, Ci, Cop, Cip, count);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(pack_weight_dual_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)wp0, (bf16*)wp1, Co, Ci, Cop, Cip, count);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, int Ci, int Cop, int Cip, void* stream) {
     HYB_CHECK_ARG(w && wp && Co > 0 && Ci > 0 && Cop % 32 == 0 && Cop >= Co && mode >= 0 && mode <= 2);
     if (mode == 2) HYB_CHECK_ARG(Ci <= 3);
@@ -466,13 +501,23 @@ extern "C" int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* w
     return 0;
 }
 
+extern "C" int hyb_conv_stats_rows(int first, int N, int H, int W, int Cop) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cop <= 0) return HYB_E_ARG;
+    int th, tw;
+    if (first || Cop % 128 != 0) { th = 16; tw = 32; }            // PG = 4 tiles
+    else if (Cop % 256 == 0) { th = 8; tw = 16; }                   // PG = 1
+    else { th = 16; tw = 16; }                                      // PG = 2
+    const long long numTiles = (long long)N * hyb_cdiv(W, tw) * hyb_cdiv(H, th);
+    return (int)(numTiles < MAX_STAT_PARTIALS ? numTiles : MAX_STAT_PARTIALS);
+}
+
 extern "C" size_t hyb_conv_stats_workspace(int Cop) { return Cop > 0 ? (size_t)MAX_STAT_PARTIALS * 2 * Cop * sizeof(float) : 0; }
 
 extern "C" int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y, float* stats, float* stats_partials, int N,
                                int H, int W, int Ci, int Cip, int Cop, void* stream) {
     HYB_CHECK_ARG(x && wp && y && N > 0 && H > 0 && W > 0 && Cop > 0 && Cop % 32 == 0);
     HYB_CHECK_ARG(!stats || stats_partials);
-    float* part = stats_partials;
+    float* part = stats_partials;          // partial rows are produced whenever a buffer is given; `stats` adds the final reduce
     HYB_CHECK_ARG((long long)N * H * W * (Cop > Cip ? Cop : Cip) < (1ll << 40));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HYB_F32) return conv_fwd_t<float>(first, x, wp, y, stats, part, N, H, W, Ci, Cip, Cop, st);

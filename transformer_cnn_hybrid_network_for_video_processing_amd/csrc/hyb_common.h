@@ -153,10 +153,13 @@ __device__ __forceinline__ float dropout_mult(unsigned long long seed, unsigned 
 // Fixed-order sum of G partial rows of n floats: column i = sum_g part[g*n + i].  Launch with 1024 threads per block
 // (32 columns x 32 row groups), grid = ceil(n / 32).  Deterministic: no float atomics.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool rows_reduce_1024(const float* __restrict__ part, int G, long long n, long long& col_out, float& sum_out) {
+__device__ __forceinline__ bool rows_reduce_1024(const float* __restrict__ part, int G, long long n, long long& col_out, float& sum_out,
+                                                 long long col_offset = 0, long long ncols = -1) {
     __shared__ float rr_red[32][33];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long long i = (long long)blockIdx.x * 32 + col;
+    const long long ii = (long long)blockIdx.x * 32 + col;
+    const long long i = (ncols < 0 || ii < ncols) ? ii + col_offset : n;      // columns [col_offset, col_offset + ncols) of rows of length n
+    __syncthreads();                                                          // allow several calls per kernel (shared scratch reuse)
     float a0 = 0.f, a1 = 0.f;
     if (i < n) {
         int g = grp;

@@ -15,10 +15,11 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop);
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop);
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* workspace, hipStream_t st);
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st);
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                   float* dbeta, void* workspace, hipStream_t st);
+                   float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
+int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, int Co, int Ci, int Cop, int Cip, hipStream_t st);
 
 namespace {
 
@@ -63,6 +64,8 @@ inline unsigned long long drop_seed(unsigned long long seed, int layer) { return
 // ----------------------------------------------------------------------------------------------------------
 // conv stage
 // ----------------------------------------------------------------------------------------------------------
+extern "C" long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop) { return first ? (long long)Cop * 64 : (long long)Cip * 9 * Cop; }
+
 extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop) {
     if (first) return hyb_stage1_fwd_workspace(dtype, Cop);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -72,23 +75,30 @@ extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int
 extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                                  int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
-                                 float* mean_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* mean_invstd, void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(x && weight && gamma && beta && running_mean && running_var && (first || y_raw) && pooled && scale_shift && mean_invstd && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(H >= 2 && W >= 2 && Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0);
     if (workspace_bytes < hyb_convstage_fwd_workspace(dtype, first, Cip, Cop)) return HYB_E_WORKSPACE;
     if (first)      // stage 1: the raw conv output is never materialised (recomputed in backward), y_raw is ignored
         return hyb_stage1_fwd(dtype, (const float*)x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci,
-                              Co, Cop, pooled, scale_shift, mean_invstd, workspace, (hipStream_t)stream);
+                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     void* wp = ws;
     float* stats = (float*)(ws + align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es));
     float* part = (float*)((char*)stats + align256(2 * (size_t)Cop * 4));
-    HYB_TRY(hyb_conv_pack_weight(dtype, first ? 2 : 0, weight, wp, Co, Ci, Cop, Cip, stream));
-    HYB_TRY(hyb_conv3x3_fwd(dtype, first, x, wp, y_raw, training ? stats : nullptr, part, N, H, W, Ci, Cip, Cop, stream));
-    HYB_TRY(hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, (long long)N * H * W, Co, Cop,
-                            scale_shift, mean_invstd, stream));
+    if (packed_bwd) HYB_TRY(hyb_conv_pack_weight_dual(dtype, weight, wp, packed_bwd, Co, Ci, Cop, Cip, (hipStream_t)stream));
+    else HYB_TRY(hyb_conv_pack_weight(dtype, 0, weight, wp, Co, Ci, Cop, Cip, stream));
+    if (training) {   // conv leaves per-workgroup partial sums; one launch sums them in a fixed order and finalises BN
+        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, x, wp, y_raw, nullptr, part, N, H, W, Ci, Cip, Cop, stream));
+        HYB_TRY(hyb_bn_stats_finalize(part, hyb_conv_stats_rows(0, N, H, W, Cop), gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                                      (long long)N * H * W, Co, Cop, scale_shift, mean_invstd, stream));
+    } else {
+        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, x, wp, y_raw, nullptr, nullptr, N, H, W, Ci, Cip, Cop, stream));
+        HYB_TRY(hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, 0, momentum, eps, (long long)N * H * W, Co, Cop,
+                                scale_shift, mean_invstd, stream));
+    }
     HYB_TRY(hyb_bn_relu_pool_fwd(dtype, y_raw, scale_shift, pooled, N, H, W, Cop, stream));
     return 0;
 }
@@ -105,8 +115,8 @@ extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H
 
 extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const float* weight,
                                  const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
-                                 int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
+                                 const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(dpooled && x && (first || y_raw) && weight && gamma && scale_shift && mean_invstd && dweight && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(first || dx);
@@ -114,7 +124,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     if (workspace_bytes < hyb_convstage_bwd_workspace(dtype, first, N, H, W, Cip, Cop)) return HYB_E_WORKSPACE;
     if (first)
         return hyb_stage1_bwd(dtype, dpooled, (const float*)x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight,
-                              dgamma, dbeta, workspace, (hipStream_t)stream);
+                              dgamma, dbeta, packed_bwd, workspace, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     float* sums = (float*)ws;                    ws += align256(2 * (size_t)Cop * 4);
@@ -125,14 +135,15 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     void* slabs = ws;
     const size_t slab_bytes = hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop);
     const long long count = (long long)N * H * W;
-    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, sum_part, N, H, W, Cop, stream));
-    HYB_TRY(hyb_bn_relu_pool_bwd_dx(dtype, dpooled, y_raw, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dgamma, dbeta, N, H,
+    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
+    HYB_TRY(hyb_bn_relu_pool_bwd_dx(dtype, dpooled, y_raw, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, nullptr, nullptr, N, H,
                                     W, Co, Cop, stream));
     HYB_TRY(hyb_conv3x3_wgrad(dtype, first, x, dyraw, dweight, N, H, W, Ci, Cip, Co, Cop, slabs, slab_bytes, stream));
     if (!first) {
         // dgrad = conv3x3 of the dense output gradient with the transposed, tap-flipped weights
-        HYB_TRY(hyb_conv_pack_weight(dtype, 1, weight, wpd, Co, Ci, Cop, Cip, stream));
-        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wpd, dx, nullptr, nullptr, N, H, W, Co, Cop, Cip, stream));
+        const void* wd = packed_bwd;
+        if (!wd) { HYB_TRY(hyb_conv_pack_weight(dtype, 1, weight, wpd, Co, Ci, Cop, Cip, stream)); wd = wpd; }
+        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wd, dx, nullptr, nullptr, N, H, W, Co, Cop, Cip, stream));
     }
     return 0;
 }

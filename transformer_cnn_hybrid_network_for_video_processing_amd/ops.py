@@ -157,18 +157,19 @@ class ConvStageFn(torch.autograd.Function):
         ws_bytes = lib.query("hyb_convstage_fwd_workspace", dt, int(first), Cip, Cop)
         ws = _ws(ws_bytes, dev)
         w = weight.detach().contiguous()
+        packed_bwd = torch.empty(lib.query("hyb_convstage_packed_bwd_elems", int(first), Cip, Cop), dtype=tdt, device=dev)
         lib.call("hyb_convstage_fwd", dt, int(first), x.data_ptr(), w.data_ptr(), gamma.detach().contiguous().data_ptr(),
                  beta.detach().contiguous().data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                  nbt.data_ptr() if nbt is not None else None, int(training), float(momentum), float(eps),
                  N, H, W, Ci, Cip, Co, Cop, y_raw.data_ptr(), pooled.data_ptr(), scale_shift.data_ptr(), mean_invstd.data_ptr(),
-                 ws.data_ptr(), ws.numel(), _stream())
-        ctx.save_for_backward(x, y_raw, scale_shift, mean_invstd, w, gamma.detach().contiguous())
+                 packed_bwd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        ctx.save_for_backward(x, y_raw, scale_shift, mean_invstd, w, gamma.detach().contiguous(), packed_bwd)
         ctx.cfg = (dt, int(first), int(training), N, H, W, Ci, Cip, Co, Cop)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        x, y_raw, scale_shift, mean_invstd, w, gamma = ctx.saved_tensors
+        x, y_raw, scale_shift, mean_invstd, w, gamma, packed_bwd = ctx.saved_tensors
         dt, first, training, N, H, W, Ci, Cip, Co, Cop = ctx.cfg
         dev = x.device
         dpooled = dpooled.contiguous()
@@ -181,7 +182,7 @@ class ConvStageFn(torch.autograd.Function):
         lib.call("hyb_convstage_bwd", dt, first, dpooled.data_ptr(), x.data_ptr(), y_raw.data_ptr(), w.data_ptr(), gamma.data_ptr(),
                  scale_shift.data_ptr(), mean_invstd.data_ptr(), training, N, H, W, Ci, Cip, Co, Cop,
                  dx.data_ptr() if dx is not None else None, dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                 ws.data_ptr(), ws.numel(), _stream())
+                 packed_bwd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
