@@ -13,28 +13,30 @@ struct AttnDims {
     int B, S, D, H, dh;
     int SK;      // S rounded up to 32 (token dimension padding)
     int dhp;     // dh rounded up to 32 (feature padding for the k32 step)
+    int ld_qkv;  // token row stride (elements) of q, k, v and dq, dk, dv (D, or 3D when they are packed as [M][3D])
+    int ld_o;    // token row stride of out / dout
 };
 
 // dst[s][c] = src[(b*S + s)*D + h*dh + c], zero padded to [SK][dhp]; row stride ld
 template <typename T>
-__device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid) {
+__device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid, int gld) {
     const int segs = d.dhp >> 3;
     for (int u = tid; u < d.SK * segs; u += 256) {
         const int s = u / segs, c = (u - s * segs) * 8;
         Vec8<T> v;
-        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * d.D + h * d.dh + c);
+        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * gld + h * d.dh + c);
         else v.zero();
         v.store(dst + s * ld + c);
     }
 }
 // dst[c][s] = src[(b*S + s)*D + h*dh + c], zero padded to [dhp][SK]; row stride ld
 template <typename T>
-__device__ __forceinline__ void stage_cols(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid) {
+__device__ __forceinline__ void stage_cols(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid, int gld) {
     const int segs = d.dhp >> 3;
     for (int u = tid; u < d.SK * segs; u += 256) {
         const int s = u / segs, c = (u - s * segs) * 8;
         Vec8<T> v;
-        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * d.D + h * d.dh + c);
+        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * gld + h * d.dh + c);
         else v.zero();
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[(c + j) * ld + s] = from_f32<T>(v.get(j));
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict_
     const int pidx = blockIdx.x, b = pidx / d.H, h = pidx % d.H;
     const int p = lane & 15, qq = lane >> 4;
 
-    stage_rows(Ql, ldq, q, d, b, h, tid);
-    stage_rows(Kl, ldq, k, d, b, h, tid);
-    stage_cols(Vt, lds_, v, d, b, h, tid);
+    stage_rows(Ql, ldq, q, d, b, h, tid, d.ld_qkv);
+    stage_rows(Kl, ldq, k, d, b, h, tid, d.ld_qkv);
+    stage_cols(Vt, lds_, v, d, b, h, tid, d.ld_qkv);
     __syncthreads();
 
     const int nt = d.SK >> 4;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) out[((long long)(b * d.S + row)) * d.D + h * d.dh + col] = from_f32<T>(acc[r]);
+                if (row < d.S) out[((long long)(b * d.S + row)) * d.ld_o + h * d.dh + col] = from_f32<T>(acc[r]);
             }
         }
     }
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
     // ---- phase A: dPd = dO V^T
     T* dOl = R1;
     T* Vl = R1 + d.SK * ldq;
-    stage_rows(dOl, ldq, dout, d, b, h, tid);
-    stage_rows(Vl, ldq, v, d, b, h, tid);
+    stage_rows(dOl, ldq, dout, d, b, h, tid, d.ld_o);
+    stage_rows(Vl, ldq, v, d, b, h, tid, d.ld_qkv);
     __syncthreads();
     for (int t = wave; t < nt * nt; t += 4) {
         const int ti = t / nt, tj = t % nt;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
     __syncthreads();
 
     // ---- phase C1: dV[key][d] = sum_query PdT[key][query] * dO^T[d][query]
-    stage_cols(R1, lds_, dout, d, b, h, tid);
+    stage_cols(R1, lds_, dout, d, b, h, tid, d.ld_o);
     __syncthreads();
     for (int t = wave; t < nt * ntd; t += 4) {
         const int ti = t / ntd, tj = t % ntd;
@@ -218,13 +220,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dv[((long long)(b * d.S + row)) * d.D + h * d.dh + col] = from_f32<T>(acc[r]);
+                if (row < d.S) dv[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
             }
         }
     }
     __syncthreads();
     // ---- phase C2: dQ[query][d] = sum_key dS[query][key] * K^T[d][key]
-    stage_cols(R1, lds_, k, d, b, h, tid);
+    stage_cols(R1, lds_, k, d, b, h, tid, d.ld_qkv);
     __syncthreads();
     for (int t = wave; t < nt * ntd; t += 4) {
         const int ti = t / ntd, tj = t % ntd;
@@ -234,13 +236,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dq[((long long)(b * d.S + row)) * d.D + h * d.dh + col] = from_f32<T>(acc[r]);
+                if (row < d.S) dq[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
             }
         }
     }
     __syncthreads();
     // ---- phase C3: dK[key][d] = sum_query dS^T[key][query] * Q^T[d][query]
-    stage_cols(R1, lds_, q, d, b, h, tid);
+    stage_cols(R1, lds_, q, d, b, h, tid, d.ld_qkv);
     __syncthreads();
     for (int t = wave; t < nt * ntd; t += 4) {
         const int ti = t / ntd, tj = t % ntd;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dk[((long long)(b * d.S + row)) * d.D + h * d.dh + col] = from_f32<T>(acc[r]);
+                if (row < d.S) dk[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
             }
         }
     }
@@ -262,6 +264,8 @@ inline bool attn_dims(AttnDims& d, int B, int S, int D, int H) {
     if (d.dh % 8 != 0 || d.dh > 128) return false;
     d.SK = (S + 31) / 32 * 32;
     d.dhp = (d.dh + 31) / 32 * 32;
+    d.ld_qkv = D;
+    d.ld_o = D;
     return true;
 }
 
@@ -327,5 +331,30 @@ extern "C" int hyb_attention_bwd(int dtype, const void* q, const void* k, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HYB_F32) return attn_bwd_t<float>(q, k, v, probs, dout, dq, dk, dv, d, p_drop, seed, st);
     if (dtype == HYB_BF16) return attn_bwd_t<bf16>(q, k, v, probs, dout, dq, dk, dv, d, p_drop, seed, st);
+    return HYB_E_ARG;
+}
+
+// Internal (same shared object): q/k/v (and dq/dk/dv) packed as [B*S][3D] -- used by hyb_encoder_{fwd,bwd}
+int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* probs, int B, int S, int D, int H, float p_drop,
+                             unsigned long long seed, hipStream_t st) {
+    AttnDims d;
+    if (!qkv || !out || !probs || !attn_dims(d, B, S, D, H)) return HYB_E_ARG;
+    d.ld_qkv = 3 * D;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const char* base = (const char*)qkv;
+    if (dtype == HYB_F32) return attn_fwd_t<float>(base, base + D * es, base + 2 * D * es, mask, out, probs, d, p_drop, seed, st);
+    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, out, probs, d, p_drop, seed, st);
+    return HYB_E_ARG;
+}
+int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int S, int D, int H,
+                             float p_drop, unsigned long long seed, hipStream_t st) {
+    AttnDims d;
+    if (!qkv || !probs || !dout || !dqkv || !attn_dims(d, B, S, D, H)) return HYB_E_ARG;
+    d.ld_qkv = 3 * D;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const char* base = (const char*)qkv;
+    char* g = (char*)dqkv;
+    if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, probs, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
+    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, probs, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
     return HYB_E_ARG;
 }

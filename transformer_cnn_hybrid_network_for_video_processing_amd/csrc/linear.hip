@@ -10,7 +10,7 @@
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st);
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
 
 namespace {
 
@@ -19,6 +19,8 @@ struct GemmGroup {
     const void* B;
     void* C;
     const float* bias;
+    const void* Amask;      // optional, same layout/type as A: A is used as A * (Amask > 0)  (ReLU backward fused into the loader)
+    float* colsum;          // optional (dW kernel): colsum[mo] = sum_r A(mo, r)   (bias gradient fused into the weight-gradient GEMM)
 };
 struct GemmArgs {
     GemmGroup g[3];
@@ -30,7 +32,8 @@ struct GemmArgs {
 constexpr int BK = 32, LDS_PAD = 8, LDS_ROW = BK + LDS_PAD;
 
 template <typename TS, typename T, bool TRANS, int ROWS>
-__device__ __forceinline__ void stage_tile(const TS* __restrict__ src, int ld, int row0, int nrows, int r0, int R, T* __restrict__ tile, int tid) {
+__device__ __forceinline__ void stage_tile(const TS* __restrict__ src, const TS* __restrict__ mask, int ld, int row0, int nrows, int r0, int R,
+                                           T* __restrict__ tile, int tid) {
     if (!TRANS) {
         if (tid < ROWS * 4) {
             const int row = tid >> 2, seg = tid & 3;
@@ -39,8 +42,15 @@ __device__ __forceinline__ void stage_tile(const TS* __restrict__ src, int ld, i
             if (gr < nrows && r + 8 <= R) {
                 Vec8<TS> s;
                 s.load(src + (long long)gr * ld + r);
+                if (mask) {
+                    Vec8<TS> mk;
+                    mk.load(mask + (long long)gr * ld + r);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v.set(j, s.get(j));
+                    for (int j = 0; j < 8; ++j) v.set(j, mk.get(j) > 0.f ? s.get(j) : 0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.set(j, s.get(j));
+                }
             } else {
                 v.zero();
             }
@@ -51,8 +61,17 @@ __device__ __forceinline__ void stage_tile(const TS* __restrict__ src, int ld, i
             const int r = tid / (ROWS / 8), seg = tid % (ROWS / 8);
             const int gr = row0 + seg * 8, rr = r0 + r;
             Vec8<TS> s;
-            if (rr < R && gr + 8 <= nrows) s.load(src + (long long)rr * ld + gr);
-            else s.zero();
+            if (rr < R && gr + 8 <= nrows) {
+                s.load(src + (long long)rr * ld + gr);
+                if (mask) {
+                    Vec8<TS> mk;
+                    mk.load(mask + (long long)rr * ld + gr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (!(mk.get(j) > 0.f)) s.set(j, 0.f);
+                }
+            } else {
+                s.zero();
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) tile[(seg * 8 + j) * LDS_ROW + r] = from_f32<T>(s.get(j));
         }
@@ -81,12 +100,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
 
     for (int r0 = 0; r0 < args.R; r0 += BK) {
         __syncthreads();
-        stage_tile<TA, T, TRANS_A, BM>(A, args.lda, m0, args.Mo, r0, args.R, As, tid);
-        stage_tile<TB, T, TRANS_B, BN>(B, args.ldb, n0, args.No, r0, args.R, Bs, tid);
+        stage_tile<TA, T, TRANS_A, BM>(A, (const TA*)grp.Amask, args.lda, m0, args.Mo, r0, args.R, As, tid);
+        stage_tile<TB, T, TRANS_B, BN>(B, (const TB*)nullptr, args.ldb, n0, args.No, r0, args.R, Bs, tid);
         __syncthreads();
+        if (grp.colsum && blockIdx.x == 0 && tid < BM) {            // bias gradient: row sums of the (masked) A tile
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) csum += to_f32<T>(As[tid * LDS_ROW + r]);
+        }
         Frag<T> a[MT], b[NTT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) frag_load(a[i], As + (wm * WM + i * 16 + p) * LDS_ROW + 8 * q);
@@ -97,6 +121,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
 #pragma unroll
             for (int j = 0; j < NTT; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
     }
+    if (grp.colsum && blockIdx.x == 0 && tid < BM && m0 + tid < args.Mo) grp.colsum[m0 + tid] = csum;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -149,13 +174,16 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const T* Mk = (const T*)grp.Amask;
     const T* arow[2];
+    const T* mrow[2];
     const T* brow[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int r = m0 + i * 16 + p; if (r > args.Mo - 1) r = args.Mo - 1;
         int c = n0 + i * 16 + p; if (c > args.No - 1) c = args.No - 1;
         arow[i] = A + (long long)r * args.lda + 8 * q;
+        mrow[i] = Mk ? Mk + (long long)r * args.lda + 8 * q : nullptr;
         brow[i] = B + (long long)c * args.ldb + 8 * q;
     }
     f32x4 acc[2][2];
@@ -170,8 +198,15 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
         const bool ok = (k0 + 8 * q + 8) <= R;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (ok) { frag_load(a[i], arow[i] + k0); frag_load(b[i], brow[i] + k0); }
-            else { frag_zero(a[i]); frag_zero(b[i]); }
+            if (ok) {
+                frag_load(a[i], arow[i] + k0); frag_load(b[i], brow[i] + k0);
+                if (Mk) {
+                    Frag<T> mk;
+                    frag_load(mk, mrow[i] + k0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (!((float)mk.v[j] > 0.f)) a[i].v[j] = (T)0.0f;
+                }
+            } else { frag_zero(a[i]); frag_zero(b[i]); }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -208,6 +243,7 @@ struct ConvertArgs {
     void* Wc[8];
     void* Wt[8];
     int N[8], K[8];
+    int ldt[8];             // row stride of the transposed copy (>= N; lets several transposes share one [K][sum N] buffer)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
@@ -229,7 +265,7 @@ __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int k = k0 + r, n = n0 + tx;
-        if (n < N && k < K) Wt[(long long)k * N + n] = from_f32<T>(tile[tx][r]);
+        if (n < N && k < K) Wt[(long long)k * a.ldt[g] + n] = from_f32<T>(tile[tx][r]);
     }
 }
 
@@ -268,7 +304,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 template <typename T>
 int linear_fwd_t(const void* x, int ldx, const float* W, const float* b, void* y, int M, int N, int K, int relu, hipStream_t st) {
     GemmArgs a{};
-    a.g[0] = GemmGroup{x, W, y, b};
+    a.g[0] = GemmGroup{x, W, y, b, nullptr, nullptr};
     a.Mo = M; a.No = N; a.R = K; a.lda = ldx; a.ldb = K; a.ldc = N; a.relu = relu; a.accumulate = 0;
     return launch_gemm<T, T, float, T, false, false>(a, 1, st);
 }
@@ -294,14 +330,14 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         if (rc) return rc;
     } else if (dx) { // dx[m][k] = sum_n dym[m][n] * W[n][k]
         GemmArgs a{};
-        a.g[0] = GemmGroup{dym, W, dx, nullptr};
+        a.g[0] = GemmGroup{dym, W, dx, nullptr, nullptr, nullptr};
         a.Mo = M; a.No = K; a.R = N; a.lda = N; a.ldb = K; a.ldc = ldx; a.relu = 0; a.accumulate = accumulate_dx;
         int rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
         if (rc) return rc;
     }
     if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]
         GemmArgs a{};
-        a.g[0] = GemmGroup{dym, x, dW, nullptr};
+        a.g[0] = GemmGroup{dym, x, dW, nullptr, nullptr, nullptr};
         a.Mo = N; a.No = K; a.R = M; a.lda = N; a.ldb = ldx; a.ldc = K; a.relu = 0; a.accumulate = 0;
         int rc = launch_gemm<T, T, T, float, true, true>(a, 1, st);
         if (rc) return rc;
@@ -325,10 +361,10 @@ int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const v
 
 // Internal (same shared object): skinny NT GEMM on pre-converted T operands, up to 3 groups.
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st) {
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask) {
     if (groups < 1 || groups > 3 || R % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return HYB_E_ARG;
     GemmArgs a{};
-    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr, Amask ? Amask[i] : nullptr, nullptr};
     a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), groups);
     if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float>), grid, dim3(256), 0, st, a);
@@ -339,14 +375,27 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
     return 0;
 }
 
+// Internal: weight + bias gradients of up to 3 Linear layers that share the input x, one launch:
+//   dW_g[n][k] = sum_m dym_g[m][n] * x[m][k],  db_g[n] = sum_m dym_g[m][n],  dym_g = dy_g * (mask_g > 0) (mask optional)
+int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
+                          float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st) {
+    if (groups < 1 || groups > 3) return HYB_E_ARG;
+    GemmArgs a{};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{dy[i], x, dW[i], nullptr, mask ? mask[i] : nullptr, db ? db[i] : nullptr};
+    a.Mo = N; a.No = K; a.R = M; a.lda = lddy; a.ldb = ldx; a.ldc = K; a.relu = 0; a.accumulate = 0;
+    if (dtype == HYB_F32) return launch_gemm<float, float, float, float, true, true>(a, groups, st);
+    if (dtype == HYB_BF16) return launch_gemm<bf16, bf16, bf16, float, true, true>(a, groups, st);
+    return HYB_E_ARG;
+}
+
 // Internal: convert up to 8 fp32 weight matrices to T (plain + transposed copies) in one launch.
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
-                        hipStream_t st) {
+                        const int* ldt, hipStream_t st) {
     if (count < 1 || count > 8) return HYB_E_ARG;
     ConvertArgs a{};
     int maxN = 0, maxK = 0;
     for (int i = 0; i < count; ++i) {
-        a.W[i] = W[i]; a.Wc[i] = Wc[i]; a.Wt[i] = Wt[i]; a.N[i] = N[i]; a.K[i] = K[i];
+        a.W[i] = W[i]; a.Wc[i] = Wc[i]; a.Wt[i] = Wt[i]; a.N[i] = N[i]; a.K[i] = K[i]; a.ldt[i] = ldt ? ldt[i] : N[i];
         if (N[i] > maxN) maxN = N[i];
         if (K[i] > maxK) maxK = K[i];
     }
@@ -374,7 +423,7 @@ int hyb_relu_mask(int dtype, const void* dy, const void* y, void* out, long long
 int hyb_linear_fwd_grouped3(int dtype, const void* const* x, const float* const* W, const float* const* b, void* const* y, int groups,
                             int M, int N, int K, int relu, hipStream_t st) {
     GemmArgs a{};
-    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{x[i], W[i], y[i], b[i]};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{x[i], W[i], y[i], b[i], nullptr, nullptr};
     a.Mo = M; a.No = N; a.R = K; a.lda = K; a.ldb = K; a.ldc = N; a.relu = relu; a.accumulate = 0;
     if (dtype == HYB_F32) return launch_gemm<float, float, float, float, false, false>(a, groups, st);
     if (dtype == HYB_BF16) return launch_gemm<bf16, bf16, float, bf16, false, false>(a, groups, st);

@@ -6,8 +6,15 @@
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st);
-int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K, hipStream_t st);
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
+                        const int* ldt, hipStream_t st);
+int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
+                          float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
+int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* probs, int B, int S, int D, int H, float p_drop,
+                             unsigned long long seed, hipStream_t st);
+int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int S, int D, int H,
+                             float p_drop, unsigned long long seed, hipStream_t st);
 int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
                       float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -29,8 +36,9 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 #define HYB_HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 struct EncLayout {       // byte offsets inside `saved` for one layer, plus per-layer stride
-    size_t x_in, q, k, v, probs, attn, o, st1, x1, hmid, f, st2, layer_bytes;
-    size_t wc[6], wt[6];   // T copies (plain / transposed) of Wq, Wk, Wv, Wo, W1, W2, converted once per forward
+    size_t x_in, qkv, probs, attn, o, st1, x1, hmid, f, st2, layer_bytes;
+    size_t wc[6], wt[6];   // T copies (plain / transposed) of Wq, Wk, Wv, Wo, W1, W2, converted once per forward;
+                           // wt[0..2] are column blocks of ONE [D][3D] matrix (K-concatenated dX of the Q, K, V projections)
 };
 inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -39,9 +47,7 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     L.x_in = take(M * D * es);
-    L.q = take(M * D * es);
-    L.k = take(M * D * es);
-    L.v = take(M * D * es);
+    L.qkv = take(M * 3 * D * es);                  // post-ReLU q | k | v, token-major [M][3D]
     L.probs = take((size_t)B * H * S * S * 4);
     L.attn = take(M * D * es);
     L.o = take(M * D * es);
@@ -51,7 +57,11 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     L.f = take(M * D * es);
     L.st2 = take(2 * M * 4);
     const size_t wsz[6] = {(size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)Hid * D, (size_t)D * Hid};
-    for (int i = 0; i < 6; ++i) { L.wc[i] = take(wsz[i] * es); L.wt[i] = take(wsz[i] * es); }
+    for (int i = 0; i < 6; ++i) L.wc[i] = take(wsz[i] * es);
+    L.wt[0] = take(3 * wsz[0] * es);
+    L.wt[1] = L.wt[0] + (size_t)D * es;
+    L.wt[2] = L.wt[0] + 2 * (size_t)D * es;
+    for (int i = 3; i < 6; ++i) L.wt[i] = take(wsz[i] * es);
     L.layer_bytes = off;
     return L;
 }
@@ -184,15 +194,16 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
             void* Wc[6]; void* Wt[6];
             for (int j = 0; j < 6; ++j) { Wc[j] = base + lay.wc[j]; Wt[j] = base + lay.wt[j]; }
             const int Ns[6] = {D, D, D, D, Hid, D}, Ks[6] = {D, D, D, D, D, Hid};
-            HYB_TRY(hyb_convert_weights(dtype, 6, Wsrc, Wc, Wt, Ns, Ks, st));
+            const int ldt[6] = {3 * D, 3 * D, 3 * D, D, Hid, D};
+            HYB_TRY(hyb_convert_weights(dtype, 6, Wsrc, Wc, Wt, Ns, Ks, ldt, st));
         }
         const void* xs[3] = {x_in, x_in, x_in};
         const void* Wq3[3] = {base + lay.wc[0], base + lay.wc[1], base + lay.wc[2]};
         const float* bs[3] = {P[1], P[3], P[5]};
-        void* ys[3] = {base + lay.q, base + lay.k, base + lay.v};
-        HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, D, 1, 0, st));                               // src L69-70
-        HYB_TRY(hyb_attention_fwd(dtype, base + lay.q, base + lay.k, base + lay.v, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D,
-                                  H, attn_p, attn_seed(seed, i), stream));                                            // src L73-84
+        void* ys[3] = {base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es};
+        HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, 3 * D, 1, 0, st));                           // src L69-70
+        HYB_TRY(hyb_attention_fwd_packed(dtype, base + lay.qkv, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p,
+                                         attn_seed(seed, i), st));                                                    // src L73-84
         { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, D, D, D, D, 0, 0, st)); }                            // src L87
         HYB_TRY(hyb_ln_residual_fwd(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
@@ -224,14 +235,10 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
     void* g1 = ws;            // d(LN input)
     void* g2 = ws + md;       // d(x1)
     void* g4 = ws + 2 * md;   // d(attn)
-    void* g5 = ws + 3 * md;   // dq
-    void* g6 = ws + 4 * md;   // dk
-    void* g7 = ws + 5 * md;   // dv
+    void* dqkv = ws + 3 * md; // d(q|k|v) packed [M][3D] (3 * md bytes reserved)
     void* gin[2] = {ws + 6 * md, ws + 7 * md};
     const size_t big = align256((size_t)M * (Hid > D ? Hid : D) * es);
     void* dh = ws + 8 * md;             // d(hmid)
-    void* scratch = ws + 8 * md + big;  // relu-masked dy
-    const size_t scratch_bytes = big;
 
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
@@ -244,21 +251,35 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         // LN2 + residual + sqrt(.5) + dropout
         HYB_TRY(hyb_ln_residual_bwd(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, G[12], G[13], M, D,
                                     (float)sqrt(0.5), layer_p, drop_seed(seed, i), stream));
-        // FFN
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.hmid, Hid, P[10], base + lay.wt[5], nullptr, g1, dh, 0, G[10], G[11], M, D, Hid, 0, nullptr, 0, st));
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x1, D, P[8], base + lay.wt[4], base + lay.hmid, dh, g2, 1, G[8], G[9], M, Hid, D, 1, scratch, scratch_bytes, st));
+        // FFN second Linear: dX = g1 . W2 (pre-transposed copy), dW/db in one launch
+        { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {dh};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
+        { const void* dy_[1] = {g1}; float* dW_[1] = {G[10]}; float* db_[1] = {G[11]};
+          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, nullptr, base + lay.hmid, dW_, db_, M, D, Hid, D, Hid, st)); }
+        // FFN first Linear (+ReLU): the mask (hmid > 0) is applied inside the GEMM loaders
+        { const void* A_[1] = {dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
+        { const void* dy_[1] = {dh}; const void* mk_[1] = {base + lay.hmid}; float* dW_[1] = {G[8]}; float* db_[1] = {G[9]};
+          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, mk_, base + lay.x1, dW_, db_, M, Hid, D, Hid, D, st)); }
         // LN1 + residual
         HYB_TRY(hyb_ln_residual_bwd(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1, gx, 0, G[12], G[13], M, D, 1.0f, 0.f,
                                     0ull, stream));
         // output projection
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.attn, D, P[6], base + lay.wt[3], nullptr, g1, g4, 0, G[6], G[7], M, D, D, 0, nullptr, 0, st));
-        // attention core
-        HYB_TRY(hyb_attention_bwd(dtype, base + lay.q, base + lay.k, base + lay.v, (const float*)(base + lay.probs), g4, g5, g6, g7, B, S, D, H,
-                                  attn_p, attn_seed(seed, i), stream));
-        // Q, K, V projections (ReLU), all three feed from the layer input
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[0], base + lay.wt[0], base + lay.q, g5, gx, 1, G[0], G[1], M, D, D, 1, scratch, scratch_bytes, st));
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[2], base + lay.wt[1], base + lay.k, g6, gx, 1, G[2], G[3], M, D, D, 1, scratch, scratch_bytes, st));
-        HYB_TRY(hyb_linear_bwd_wt(dtype, base + lay.x_in, D, P[4], base + lay.wt[2], base + lay.v, g7, gx, 1, G[4], G[5], M, D, D, 1, scratch, scratch_bytes, st));
+        { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
+        { const void* dy_[1] = {g1}; float* dW_[1] = {G[6]}; float* db_[1] = {G[7]};
+          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, nullptr, base + lay.attn, dW_, db_, M, D, D, D, D, st)); }
+        // attention core: d(q|k|v) packed [M][3D]
+        HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
+                                         attn_seed(seed, i), st));
+        // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM, one grouped dW/db launch
+        { const void* A_[1] = {dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }
+        { const char* dq_ = (const char*)dqkv; const char* qk_ = base + lay.qkv;
+          const void* dy_[3] = {dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
+          const void* mk_[3] = {qk_, qk_ + (size_t)D * es, qk_ + 2 * (size_t)D * es};
+          float* dW_[3] = {G[0], G[2], G[4]}; float* db_[3] = {G[1], G[3], G[5]};
+          HYB_TRY(hyb_linear_dw_grouped(dtype, 3, dy_, mk_, base + lay.x_in, dW_, db_, M, D, D, 3 * D, D, st)); }
         gA = gx;
     }
     return 0;
