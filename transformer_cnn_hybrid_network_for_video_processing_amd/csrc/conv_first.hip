@@ -53,11 +53,21 @@ struct S1Args {
     int training;
     float inv_count;
     int tilesX, tilesY, numTiles;
+    float inv_tpi, inv_tx;   // 1 / (tilesX*tilesY), 1 / tilesX: tile -> (n, ty, tx) without integer division
     int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
 };
 
 constexpr int S1_IW = S1_TW + 8;               // image row in LDS: columns tx0-4 .. tx0+35 (aligned float4 segments)
 constexpr int S1_IMG = S1_HH * S1_IW;          // 400 pixels x 4 channels
+
+// tile -> (image, tile row, tile col) with float reciprocals: exact while numTiles < 2^20 and the divisors are <= 4096
+__device__ __forceinline__ void s1_decode(const S1Args& a, int tile, int& n, int& ty0, int& tx0) {
+    n = (int)(((float)tile + 0.5f) * a.inv_tpi);
+    const int trem = tile - n * (a.tilesX * a.tilesY);
+    const int tr = (int)(((float)trem + 0.5f) * a.inv_tx);
+    ty0 = tr * S1_TH;
+    tx0 = (trem - tr * a.tilesX) * S1_TW;
+}
 
 // 8 K-elements of one pixel's im2col row for k-step 0 (taps 2q, 2q+1) or k-step 1 (tap 8 for q == 0, else zero),
 // read straight from the halo image [row][col][4 channels]
@@ -134,9 +144,13 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                 c_sc[t][r] = a.ss[ch]; c_sh[t][r] = a.ss[Cop + ch];
                 if (MODE >= 2) { c_mean[t][r] = a.mi[ch]; c_inv[t][r] = a.mi[Cop + ch]; }
                 if (MODE == 3) {
-                    c_k[t][r] = (ch < a.Co ? a.gamma[ch] : 0.f) * a.mi[Cop + ch];
-                    c_m1[t][r] = a.training ? a.sums[ch] * a.inv_count : 0.f;
-                    c_m2[t][r] = a.training ? a.sums[Cop + ch] * a.inv_count : 0.f;
+                    // dyraw = k*(dy - m1 - xhat*m2), xhat = (y - mean)*inv  ==  A1*y + A0 + k*dy
+                    const float k = (ch < a.Co ? a.gamma[ch] : 0.f) * a.mi[Cop + ch];
+                    const float m1 = a.training ? a.sums[ch] * a.inv_count : 0.f;
+                    const float m2 = a.training ? a.sums[Cop + ch] * a.inv_count : 0.f;
+                    c_k[t][r] = k;
+                    c_m2[t][r] = -k * m2 * a.mi[Cop + ch];                       // A1
+                    c_m1[t][r] = -k * m1 + k * m2 * a.mi[Cop + ch] * a.mi[ch];   // A0
                 }
             }
     }
@@ -159,9 +173,8 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     f32x4 pf[4];
     auto prefetch = [&](int tile) {
         if (tid >= 100) return;
-        const int n = tile / (a.tilesX * a.tilesY);
-        const int trem = tile - n * (a.tilesX * a.tilesY);
-        const int ty0 = (trem / a.tilesX) * S1_TH, tx0 = (trem % a.tilesX) * S1_TW;
+        int n, ty0, tx0;
+        s1_decode(a, tile, n, ty0, tx0);
         const int row = tid / 10, seg = tid - row * 10;
         const int gy = ty0 + row - 1, gx0 = tx0 - 4 + 4 * seg;
 #pragma unroll
@@ -180,12 +193,23 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             pf[c] = v;
         }
     };
-    if ((int)blockIdx.x < a.numTiles) prefetch(blockIdx.x);
+    // MODE >= 2: this lane's dpooled values (window (wy, wx) of the wave's 8x8 block) are prefetched one tile ahead too
+    Vec8<T> gpf[NT / 2];
+    auto prefetch_dp = [&](int tile) {
+        int n, ty0, tx0;
+        s1_decode(a, tile, n, ty0, tx0);
+        const int oy = (ty0 + 2 * wy) >> 1, ox = (tx0 + wave * 8 + 2 * wx) >> 1;
+        const T* dsrc = (const T*)a.dp + ((long long)(n * Ho + oy) * Wo + ox) * Cop + co_base + q * (NT * 4);
+#pragma unroll
+        for (int h8 = 0; h8 < NT / 2; ++h8) {
+            if (oy < Ho && ox < Wo) gpf[h8].load(dsrc + h8 * 8); else gpf[h8].zero();
+        }
+    };
+    if ((int)blockIdx.x < a.numTiles) { prefetch(blockIdx.x); if (MODE >= 2) prefetch_dp(blockIdx.x); }
 
     for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-        const int n = tile / (a.tilesX * a.tilesY);
-        const int trem = tile - n * (a.tilesX * a.tilesY);
-        const int ty0 = (trem / a.tilesX) * S1_TH, tx0 = (trem % a.tilesX) * S1_TW;
+        int n, ty0, tx0;
+        s1_decode(a, tile, n, ty0, tx0);
         __syncthreads();                                   // previous tile done with img / P / dyt
         if (tid < 100) {
 #pragma unroll
@@ -197,7 +221,15 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < a.numTiles) prefetch(tile + gridDim.x);      // in flight under this tile's work
+        Vec8<T> gcur[NT / 2];
+        if (MODE >= 2) {
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) gcur[h8] = gpf[h8];
+        }
+        if (tile + (int)gridDim.x < a.numTiles) {                                // in flight under this tile's work
+            prefetch(tile + gridDim.x);
+            if (MODE >= 2) prefetch_dp(tile + gridDim.x);
+        }
         if (MODE == 3) {   // im2col for the wgrad B operand: pixel tid, 9 taps x 4 channels
             const int ty = tid >> 5, tx = tid & 31;
 #pragma unroll
@@ -256,11 +288,12 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             }
         }
         if (MODE >= 2) {
-            const T* dsrc = (const T*)a.dp + ((long long)(n * Ho + oy) * Wo + ox) * Cop + co_base + q * (NT * 4);
+            bool pixvalid[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pixvalid[j] = (gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W;
 #pragma unroll
             for (int h8 = 0; h8 < NT / 2; ++h8) {
-                Vec8<T> g;
-                if (win_ok) g.load(dsrc + h8 * 8); else g.zero();
+                const Vec8<T> g = gcur[h8];
                 Vec8<T> o[4];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -281,11 +314,11 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                         acc2[t][r] += dy * (ysel - c_mean[t][r]) * c_inv[t][r];
                     }
                     if (MODE == 3) {
+                        const float kdy = c_k[t][r] * dy;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const bool valid = (gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W;
-                            const float xhat = (acc[j][t][r] - c_mean[t][r]) * c_inv[t][r];
-                            o[j].set(e, valid ? c_k[t][r] * ((am == j ? dy : 0.f) - c_m1[t][r] - xhat * c_m2[t][r]) : 0.f);
+                            const float base = fmaf(acc[j][t][r], c_m2[t][r], c_m1[t][r]);
+                            o[j].set(e, pixvalid[j] ? (am == j ? base + kdy : base) : 0.f);
                         }
                     }
                 }
@@ -447,6 +480,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.pooled = pooled; a.part = part;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
+    a.inv_tpi = 1.0f / (float)(a.tilesX * a.tilesY); a.inv_tx = 1.0f / (float)a.tilesX;
     a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
@@ -486,6 +520,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
     a.inv_count = 1.0f / (float)((long long)N * H * W);
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
+    a.inv_tpi = 1.0f / (float)(a.tilesX * a.tilesY); a.inv_tx = 1.0f / (float)a.tilesX;
     a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
