@@ -118,10 +118,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* __restrict__ dp, const T* __restrict__ y,
                                                                       const float* __restrict__ ss, const float* __restrict__ mi,
                                                                       float* __restrict__ sums, int N, int H, int W, int Cop) {
-    extern __shared__ float red[];                 // [2][Cop]
+    extern __shared__ float red[];                 // [256 threads][16] per-thread partials, combined in a fixed order
     const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
-    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
     const int nthr = row_threads(OCT);
     if ((int)threadIdx.x < nthr) {
         const int oc = threadIdx.x % OCT;
@@ -157,13 +155,18 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* _
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            atomicAdd(&red[oc * 8 + j], a1[j]);
-            atomicAdd(&red[Cop + oc * 8 + j], a2[j]);
+            red[threadIdx.x * 16 + j] = a1[j];
+            red[threadIdx.x * 16 + 8 + j] = a2[j];
         }
     }
     __syncthreads();
-    // one partial row per block: summed in a fixed order by the caller (no global float atomics)
-    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) sums[(long long)blockIdx.x * 2 * Cop + i] = red[i];
+    // one partial row per block (no float atomics anywhere): entry (which, ch) = sum over the threads that own octet ch/8
+    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) {
+        const int which = i / Cop, ch = i % Cop, o8 = ch >> 3, j = ch & 7;
+        float acc = 0.f;
+        for (int t = o8; t < nthr; t += OCT) acc += red[t * 16 + which * 8 + j];
+        sums[(long long)blockIdx.x * 2 * Cop + i] = acc;
+    }
 }
 
 // pass 2: dense gradient w.r.t. the raw conv output.
@@ -400,7 +403,7 @@ extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const
     HYB_CHECK_ARG(dpooled && y && ss && mi && sums && partials && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0 && Cop / 8 <= 256);
     const int grid = row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 2 * (size_t)Cop * sizeof(float);
+    const size_t lds = 256 * 16 * sizeof(float);
     HYB_DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, partials, N, H, W, Cop),
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, partials, N, H, W, Cop));

@@ -123,9 +123,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             P[pix * S1_PS + k] = from_f32<T>(0.f);
         }
     }
-    if (MODE == 0 || MODE == 2) {
-        for (int i = tid; i < 2 * NT * 16; i += 256) wgstat[i] = 0.f;
-    }
+    // (modes 0, 2) per-wave slots [4][2][NT*16]: no atomics, fixed-order combine at the end (bit-reproducible)
 
     Frag<T> w0[NT], w1[NT];
 #pragma unroll
@@ -358,14 +356,16 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             for (int r = 0; r < 4; ++r) {
                 const float s1 = group16_sum(acc1[t][r]), s2 = group16_sum(acc2[t][r]);
                 if (p == 0) {
-                    atomicAdd(&wgstat[q * (NT * 4) + t * 4 + r], s1);
-                    atomicAdd(&wgstat[NT * 16 + q * (NT * 4) + t * 4 + r], s2);
+                    wgstat[(wave * 2 + 0) * (NT * 16) + q * (NT * 4) + t * 4 + r] = s1;
+                    wgstat[(wave * 2 + 1) * (NT * 16) + q * (NT * 4) + t * 4 + r] = s2;
                 }
             }
         __syncthreads();
         for (int i = tid; i < 2 * NT * 16; i += 256) {
             const int which = i / (NT * 16), cl = i % (NT * 16);
-            a.part[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = wgstat[i];
+            const float v = (wgstat[(0 * 2 + which) * (NT * 16) + cl] + wgstat[(1 * 2 + which) * (NT * 16) + cl]) +
+                            (wgstat[(2 * 2 + which) * (NT * 16) + cl] + wgstat[(3 * 2 + which) * (NT * 16) + cl]);
+            a.part[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = v;
         }
     }
     if (MODE == 3) {
@@ -423,7 +423,7 @@ template <typename T, int NT, int MODE>
 size_t s1_lds_bytes() {
     size_t el = (size_t)S1_IMG * 4;
     if (MODE == 3) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
-    return el * sizeof(T) + 2 * NT * 16 * sizeof(float) + 64;
+    return el * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
 }
 
 template <typename T, int NT, int MODE>

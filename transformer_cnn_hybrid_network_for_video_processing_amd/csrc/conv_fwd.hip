@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
     // swizzle of the fragment slot: depends on the lane and the tap only (patch origins are multiples of 4 pixels)
     const int sw_row = py, sw_col = 2 * py + px;
 
-    // BN sums of this workgroup live in LDS behind the halo image: [2][CB*NT*16] floats, updated once per tile
+    // BN sums live in LDS behind the halo image: one private slot per wave [4][2][NT*16] (single owner lane per entry, so the
+    // per-tile updates need no atomics and the result is bit-reproducible); combined in a fixed order at the end
     float* wgstat = reinterpret_cast<float*>(smem_raw + (size_t)HP * CK * sizeof(T));
     if (STATS) {
-        for (int i = tid; i < 2 * CB * NT * 16; i += 256) wgstat[i] = 0.f;
+        for (int i = tid; i < 4 * 2 * NT * 16; i += 256) wgstat[i] = 0.f;
     }
 
     auto stage = [&](int n, int ty0, int tx0, int cb0) {
@@ -185,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                 for (int r = 0; r < 4; ++r) {
                     const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
                     if (p == 0) {
-                        const int cl = cb * (NT * 16) + q * (NT * 4) + t * 4 + r;
-                        atomicAdd(&wgstat[cl], a);
-                        atomicAdd(&wgstat[CB * NT * 16 + cl], b);
+                        const int cl = q * (NT * 4) + t * 4 + r;
+                        wgstat[(wave * 2 + 0) * (NT * 16) + cl] += a;
+                        wgstat[(wave * 2 + 1) * (NT * 16) + cl] += b;
                     }
                 }
         }
@@ -197,7 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
         __syncthreads();
         for (int i = tid; i < 2 * CB * NT * 16; i += 256) {
             const int which = i / (CB * NT * 16), cl = i % (CB * NT * 16);
-            stats[((long long)blockIdx.x * 2 + which) * Cop + blockIdx.y * (CB * NT * 16) + cl] = wgstat[i];
+            const int cbi = cl / (NT * 16), c16 = cl % (NT * 16);
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) acc += wgstat[((g * CB + cbi) * 2 + which) * (NT * 16) + c16];     // wave = pg*CB + cb
+            stats[((long long)blockIdx.x * 2 + which) * Cop + blockIdx.y * (CB * NT * 16) + cl] = acc;
         }
     }
 }
@@ -371,7 +376,7 @@ constexpr int MAX_STAT_PARTIALS = 512;
 template <typename T, int NT, int CB, int PG, int CK>
 int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
     constexpr int TH = 4 * TileGeom<PG>::PHP, TW = 4 * TileGeom<PG>::PWP, HP = (TH + 2) * (TW + 2);
-    const size_t lds = (size_t)HP * CK * sizeof(T) + 2 * CB * NT * 16 * sizeof(float);
+    const size_t lds = (size_t)HP * CK * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float);
     const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
     const int gy = Cop / (CB * NT * 16);
