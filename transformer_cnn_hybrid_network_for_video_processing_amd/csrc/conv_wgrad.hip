@@ -37,9 +37,24 @@ __device__ __forceinline__ void tr_frag(Frag<float>& f, const float* base, int s
     }
 }
 
-template <typename T, int CIT>
+// Inputs of the fused BatchNorm/ReLU/MaxPool backward (FUSE = true): the gradient tile is computed on the fly from the raw conv
+// output y, the pooled-output gradient dp and per-channel constants, instead of being read from a materialised dyraw tensor.
+struct WgradFuse {
+    const void* y;          // raw conv output NHWC T [N,H,W,Cop]
+    const void* dp;         // dpooled NHWC T [N,H/2,W/2,Cop]
+    const float* ss;        // scale/shift [2][Cop]
+    const float* mi;        // mean/invstd [2][Cop]
+    const float* gamma;     // [Co]
+    const float* sums;      // [2][Cop]: sum dy, sum dy*xhat
+    void* dyraw_out;        // optional: dense gradient written once (by the ci-block 0 workgroups) for the dgrad conv
+    int Co, training;
+    float inv_count;
+};
+
+template <typename T, int CIT, bool FUSE>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ slab,
-                                                            int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles) {
+                                                            int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles,
+                                                            WgradFuse fz) {
     constexpr int NCT = CIT;                       // co tiles per wave (waves = CIT ci tiles x 4/CIT co groups)
     constexpr int XCOLS = CIT * 16, X_STRIDE = XCOLS + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -52,6 +67,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
     const int g = lane >> 4;
     const int nCiBlk = Cip / XCOLS;
     const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * XCOLS;
+    // FUSE: per-channel constants of this workgroup's 64 output channels, in LDS behind the two tiles:
+    //   v = sc*y + sh (argmax / ReLU gate);  dyraw = A1*y + A0 + (argmax ? k*dy : 0)
+    float* cst = reinterpret_cast<float*>(xh + WG_HP * X_STRIDE);          // [5][64]: sc, sh, k, A1, A0
+    if (FUSE) {
+        if (tid < 64) {
+            const int ch = co0 + tid;
+            float sc = 0.f, sh = 0.f, k = 0.f, a1 = 0.f, a0 = 0.f;
+            if (ch < Cop) {
+                sc = fz.ss[ch]; sh = fz.ss[Cop + ch];
+                const float mean = fz.mi[ch], inv = fz.mi[Cop + ch];
+                k = (ch < fz.Co ? fz.gamma[ch] : 0.f) * inv;
+                const float m1 = fz.training ? fz.sums[ch] * fz.inv_count : 0.f, m2 = fz.training ? fz.sums[Cop + ch] * fz.inv_count : 0.f;
+                a1 = -k * m2 * inv;
+                a0 = -k * m1 + k * m2 * inv * mean;
+            }
+            cst[tid] = sc; cst[64 + tid] = sh; cst[128 + tid] = k; cst[192 + tid] = a1; cst[256 + tid] = a0;
+        }
+    }
 
     f32x4 acc[9][NCT];
 #pragma unroll
@@ -64,14 +97,61 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
         const int trem = tile - n * (tilesX * tilesY);
         const int ty0 = (trem / tilesX) * WG_TH, tx0 = (trem % tilesX) * WG_TW;
         __syncthreads();
-        // stage dy tile: 128 pixels x 64 channels
-        for (int u = tid; u < WG_TH * WG_TW * (DY_COLS / 8); u += 256) {
-            const int pix = u >> 3, s = u & 7;
-            const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
-            Vec8<T> v;
-            if (gy < H && gx < W && co0 + 8 * s < Cop) v.load(dy + ((long long)(n * H + gy) * W + gx) * Cop + co0 + 8 * s);
-            else v.zero();
-            v.store(dyt + pix * DY_STRIDE + 8 * s);
+        if (!FUSE) {
+            // stage dy tile: 128 pixels x 64 channels
+            for (int u = tid; u < WG_TH * WG_TW * (DY_COLS / 8); u += 256) {
+                const int pix = u >> 3, s = u & 7;
+                const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
+                Vec8<T> v;
+                if (gy < H && gx < W && co0 + 8 * s < Cop) v.load(dy + ((long long)(n * H + gy) * W + gx) * Cop + co0 + 8 * s);
+                else v.zero();
+                v.store(dyt + pix * DY_STRIDE + 8 * s);
+            }
+        } else {
+            // one thread per (2x2 pooling window, 8-channel octet): 32 windows x 8 octets = 256 units
+            const int oct = tid & 7, win = tid >> 3, wyy = win >> 3, wxx = win & 7;
+            const int gy0 = ty0 + 2 * wyy, gx0 = tx0 + 2 * wxx;
+            const int Ho = H >> 1, Wo = W >> 1;
+            const bool chok = co0 + 8 * oct < Cop;
+            const bool win_ok = (gy0 >> 1) < Ho && (gx0 >> 1) < Wo;
+            const T* yb = (const T*)fz.y + co0 + 8 * oct;
+            Vec8<T> yv[4], g;
+            bool pv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = gy0 + (j >> 1), gx = gx0 + (j & 1);
+                pv[j] = chok && gy < H && gx < W;
+                if (pv[j]) yv[j].load(yb + ((long long)(n * H + gy) * W + gx) * Cop); else yv[j].zero();
+            }
+            if (chok && win_ok) g.load((const T*)fz.dp + ((long long)(n * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1)) * Cop + co0 + 8 * oct);
+            else g.zero();
+            Vec8<T> o[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = oct * 8 + e;
+                const float sc = cst[c], sh = cst[64 + c], kk = cst[128 + c], a1 = cst[192 + c], a0 = cst[256 + c];
+                float vmax = yv[0].get(e) * sc + sh;
+                int am = 0;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const float v = yv[j].get(e) * sc + sh;
+                    if (v > vmax) { vmax = v; am = j; }
+                }
+                const float kdy = (vmax > 0.f && win_ok) ? kk * g.get(e) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float base = fmaf(yv[j].get(e), a1, a0);
+                    o[j].set(e, pv[j] ? (am == j ? base + kdy : base) : 0.f);
+                }
+            }
+            const bool writer = fz.dyraw_out && (blockIdx.y % nCiBlk) == 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ly = 2 * wyy + (j >> 1), lx = 2 * wxx + (j & 1);
+                o[j].store(dyt + (ly * WG_TW + lx) * DY_STRIDE + 8 * oct);
+                if (writer && pv[j])
+                    o[j].store((T*)fz.dyraw_out + ((long long)(n * H + ty0 + ly) * W + tx0 + lx) * Cop + co0 + 8 * oct);
+            }
         }
         // stage x halo: 180 pixels x XCOLS channels
         for (int u = tid; u < WG_HP * (XCOLS / 8); u += 256) {
@@ -210,7 +290,7 @@ inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
 
 template <typename T>
 int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* ws,
-            size_t ws_bytes, hipStream_t st) {
+            size_t ws_bytes, hipStream_t st, const WgradFuse* fz = nullptr) {
     const WgradPlan p = wgrad_plan(first, N, H, W, Cip, Cop);
     if (ws_bytes < (size_t)p.S * p.per_slab * sizeof(float)) return HYB_E_WORKSPACE;
     float* slab = (float*)ws;
@@ -223,13 +303,17 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
         hipLaunchKernelGGL(conv3x3_wgrad_first_kernel<T>, grid, dim3(256), 0, st, (const float*)x, (const T*)dy, slab, N, H, W, Ci, Cop, tilesX,
                            tilesY, numTiles);
     } else if (p.cit == 4) {
-        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (64 + 16)) * sizeof(T);
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 4>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop, tilesX,
-                           tilesY, numTiles);
+        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (64 + 16)) * sizeof(T) + 5 * 64 * sizeof(float);
+        if (fz) hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 4, true>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop,
+                                   tilesX, tilesY, numTiles, *fz);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 4, false>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop,
+                                tilesX, tilesY, numTiles, WgradFuse{});
     } else {
-        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (32 + 16)) * sizeof(T);
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 2>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop, tilesX,
-                           tilesY, numTiles);
+        const size_t lds = (size_t)(WG_TH * WG_TW * DY_STRIDE + WG_HP * (32 + 16)) * sizeof(T) + 5 * 64 * sizeof(float);
+        if (fz) hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 2, true>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop,
+                                   tilesX, tilesY, numTiles, *fz);
+        else hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, 2, false>), grid, dim3(256), lds, st, (const T*)x, (const T*)dy, slab, N, H, W, Cip, Cop,
+                                tilesX, tilesY, numTiles, WgradFuse{});
     }
     if (hook) hipEventRecord(hook->ev1, st);
     HYB_LAUNCH_CHECK();
@@ -240,6 +324,16 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
 }
 
 }  // namespace
+
+// Internal: weight gradient with the BatchNorm/ReLU/MaxPool backward fused into the tile staging (non-first stages)
+int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
+                            const float* sums, int training, long long count, void* dyraw_out, float* dw, int N, int H, int W, int Ci,
+                            int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    WgradFuse fz{y, dp, ss, mi, gamma, sums, dyraw_out, Co, training, 1.0f / (float)count};
+    if (dtype == HYB_F32) return wgrad_t<float>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
+    if (dtype == HYB_BF16) return wgrad_t<bf16>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
+    return HYB_E_ARG;
+}
 
 extern "C" size_t hyb_conv3x3_wgrad_workspace(int first, int N, int H, int W, int Cip, int Cop) {
     if (N <= 0 || H <= 0 || W <= 0 || Cop <= 0 || Cop % 32 != 0 || (!first && (Cip <= 0 || Cip % 32 != 0))) return 0;

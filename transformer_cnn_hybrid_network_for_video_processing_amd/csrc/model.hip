@@ -26,6 +26,9 @@ int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* 
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
                    float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
+int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
+                            const float* sums, int training, long long count, void* dyraw_out, float* dw, int N, int H, int W, int Ci,
+                            int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st);
 int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, int Co, int Ci, int Cop, int Cip, hipStream_t st);
 
 namespace {
@@ -146,9 +149,9 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     const size_t slab_bytes = hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop);
     const long long count = (long long)N * H * W;
     HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
-    HYB_TRY(hyb_bn_relu_pool_bwd_dx(dtype, dpooled, y_raw, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, nullptr, nullptr, N, H,
-                                    W, Co, Cop, stream));
-    HYB_TRY(hyb_conv3x3_wgrad(dtype, first, x, dyraw, dweight, N, H, W, Ci, Cip, Co, Cop, slabs, slab_bytes, stream));
+    // dense BN/ReLU/pool backward is computed inside the wgrad tile staging; the tile is also written once (dyraw) for dgrad
+    HYB_TRY(hyb_conv3x3_wgrad_fused(dtype, x, y_raw, dpooled, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dweight, N, H, W,
+                                    Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream));
     if (!first) {
         // dgrad = conv3x3 of the dense output gradient with the transposed, tap-flipped weights
         const void* wd = packed_bwd;
