@@ -144,7 +144,9 @@ def instep_kernel_table(args, step_fn, nsteps=8):
         io = float(N * H * H * (ci + co) * 2)
         specs.append((f"conv{li + 1}_fwd", 1, ci, co, "conv3x3_nhwc_kernel", flops, io))
         specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_nhwc_kernel", flops, io))
-        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "conv3x3_wgrad_kernel<%s>" % ("4" if ci % 64 == 0 else "2"), flops, io))
+        # the wgrad kernel is fused with the BN/ReLU/pool backward: reads x, raw conv output y, dpooled; writes the dense gradient + dW
+        io_w = float(N * H * H * (ci + 2 * co) * 2 + N * (H // 2) * (H // 2) * co * 2)
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "conv3x3_wgrad_kernel<%s>" % ("4" if ci % 64 == 0 else "2"), flops, io_w))
         H //= 2
     evs = []
     for slot, sp in enumerate(specs):
