@@ -9,6 +9,7 @@
 // Workgroup = 4 waves = CB channel blocks x PG pixel groups; the grid walks image tiles
 // (persistent, grid-stride) and folds the BatchNorm batch statistics (sum, sum of squares per
 // output channel, UNet.py:59) into the epilogue from the fp32 accumulators.
+#include <stdlib.h>
 #include "hyb_common.h"
 
 namespace {
@@ -31,7 +32,7 @@ __device__ __forceinline__ int halo_swz(int hp, int hy, int spf) {
 template <int PG> __device__ __host__ constexpr int patch_row(int pg, int m) { return PG == 4 ? pg : (PG == 2 ? pg * 2 + m / 4 : m / 4); }
 template <int PG> __device__ __host__ constexpr int patch_col(int m) { return PG == 4 ? m : m % 4; }
 
-template <typename T, int NT, int CB, int PG, int CK, bool STATS>
+template <typename T, int NT, int CB, int PG, int CK, bool STATS, bool WLDS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                            T* __restrict__ y, float* __restrict__ stats,
                                                            int N, int H, int W, int Cip, int Cop,
@@ -71,6 +72,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
     if (STATS) {
         for (int i = tid; i < 4 * 2 * NT * 16; i += 256) wgstat[i] = 0.f;
     }
+    // WLDS: per-tap weight slices [CB*NT*16 co][32 ci] shared by the workgroup, ring of 3 slots behind the stat slots
+    constexpr int CBW = CB * NT * 16;                       // output channels per workgroup
+    constexpr int WSLOT = CBW * 32;                         // elements per ring slot
+    constexpr int WU = (CBW * 4 + 255) / 256;               // 16-byte units per thread per slice
+    T* wring = reinterpret_cast<T*>(smem_raw + (size_t)HP * CK * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float));
 
     auto stage = [&](int n, int ty0, int tx0, int cb0) {
         for (int u = tid; u < HP * SPF; u += 256) {
@@ -108,6 +114,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                 stage(n, ty0, tx0, cblk * CK);
                 __syncthreads();
             }
+            if constexpr (WLDS) {
+                constexpr int NSTEP = NCHUNK * 9;
+                const T* wsrc = wp + (long long)(blockIdx.y * CBW) * wrow + (long long)(cblk * NCHUNK) * 288;   // step s: + s*32
+                Vec8<T> wreg[WU];
+                auto wload = [&](int sidx) {
+#pragma unroll
+                    for (int k = 0; k < WU; ++k) {
+                        const int u = tid + k * 256;
+                        if (u < CBW * 4) wreg[k].load(wsrc + (long long)(u >> 2) * wrow + sidx * 32 + (u & 3) * 8);
+                    }
+                };
+                auto wstore = [&](int slot) {
+#pragma unroll
+                    for (int k = 0; k < WU; ++k) {
+                        const int u = tid + k * 256;
+                        if (u < CBW * 4) {
+                            const int col = u >> 2, seg = u & 3, key = (col / (NT * 4)) & 3;
+                            const int f = (4 - key) & 3;                                    // F = [0, 3, 2, 1]
+                            wreg[k].store(wring + slot * WSLOT + col * 32 + ((seg ^ f) << 3));
+                        }
+                    }
+                };
+                wload(0);
+                wstore(0);
+                if (NSTEP > 1) wload(1);
+                const int akey = (4 - (p >> 2)) & 3;
+                int aoff[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) aoff[t] = (cb * (NT * 16) + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * 32 + ((q ^ akey) << 3);
+#pragma unroll 1
+                for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int sidx = chunk * 9 + tap;
+                        const int kh = tap / 3, kw = tap % 3;
+                        if (sidx + 1 < NSTEP) wstore((sidx + 1) % 3);
+                        if (sidx + 2 < NSTEP) wload(sidx + 2);
+                        __syncthreads();
+                        Frag<T> a[NT];
+                        const T* aslot = wring + (sidx % 3) * WSLOT;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) frag_load(a[t], aslot + aoff[t]);
+                        int sw = ((sw_row + kh) & 1) << 1;
+                        if (SPF == 8) sw |= (((sw_col + 2 * kh + kw) >> 1) & 1) << 2;
+                        if (SPF >= 16) sw |= ((sw_col + 2 * kh + kw) & 3) << 2;
+                        const T* bptr = halo + lane_el + (kh * HW_ + kw) * CK + (((chunk * 4 + q) ^ sw) << 3);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            Frag<T> b;
+                            frag_load(b, bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a[t], b, acc[m][t]);
+                        }
+                    }
+                }
+            } else
 #pragma unroll 1
             for (int chunk = 0; chunk < NCHUNK; ++chunk) {
                 const T* wbase[NT];
@@ -373,10 +435,10 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const float* __restr
 
 constexpr int MAX_STAT_PARTIALS = 512;
 
-template <typename T, int NT, int CB, int PG, int CK>
+template <typename T, int NT, int CB, int PG, int CK, bool WLDS = false>
 int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
     constexpr int TH = 4 * TileGeom<PG>::PHP, TW = 4 * TileGeom<PG>::PWP, HP = (TH + 2) * (TW + 2);
-    const size_t lds = (size_t)HP * CK * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float);
+    const size_t lds = (size_t)HP * CK * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + (WLDS ? 3 * (size_t)CB * NT * 16 * 32 * sizeof(T) : 0);
     const int tilesX = hyb_cdiv(W, TW), tilesY = hyb_cdiv(H, TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
     const int gy = Cop / (CB * NT * 16);
@@ -384,20 +446,20 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
     if (lds > 64 * 1024) {
-        const void* f = part ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>;
+        const void* f = part ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true, WLDS> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false, WLDS>;
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     HybProfileHook* hook = hyb_find_hook(1, Cip, Cop);
     if (hook) hipEventRecord(hook->ev0, st);
     if (part) {
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true, WLDS>), grid, dim3(256), lds, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
         if (hook) hipEventRecord(hook->ev1, st);
         HYB_LAUNCH_CHECK();
         if (stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, gx, 2 * Cop);
     } else {
-        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
+        hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false, WLDS>), grid, dim3(256), lds, st, x, wp, y, stats, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles);
         if (hook) hipEventRecord(hook->ev1, st);
     }
@@ -409,6 +471,14 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
 template <typename T, int NT, int CB, int PG>
 int launch_conv(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
     constexpr int ES = (int)sizeof(T);
+    if constexpr (ES == 2) {
+        static const int wlds = getenv("HYB_CONV_WLDS") ? atoi(getenv("HYB_CONV_WLDS")) : 1;
+        if (wlds) {     // default: weight fragments come from an LDS ring shared by the workgroup (HYB_CONV_WLDS=0: per-wave global loads)
+            if constexpr (PG == 1) { if (Cip % 64 == 0) return launch_conv_ck<T, NT, CB, PG, 64, true>(x, wp, y, stats, part, N, H, W, Cip, Cop, st); }
+            if constexpr (PG == 2) { if (Cip % 64 == 0) return launch_conv_ck<T, NT, CB, PG, 64, true>(x, wp, y, stats, part, N, H, W, Cip, Cop, st); }
+            return launch_conv_ck<T, NT, CB, PG, 32, true>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
+        }
+    }
     if constexpr (PG == 1) {
         if (Cip % 128 == 0 && ES == 2) return launch_conv_ck<T, NT, CB, PG, 128>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
         if (Cip % 64 == 0) return launch_conv_ck<T, NT, CB, PG, 64>(x, wp, y, stats, part, N, H, W, Cip, Cop, st);
@@ -445,7 +515,8 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
         return 0;
     }
     HYB_CHECK_ARG(Cip % 32 == 0);
-    if (Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
+    static const int cfg = getenv("HYB_CONV_CFG") ? atoi(getenv("HYB_CONV_CFG")) : 0;
+    if (cfg != 2 && Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
     if (Cop % 128 == 0) return launch_conv<T, 4, 2, 2>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
     if (Cop % 64 == 0) return launch_conv<T, 4, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
     return launch_conv<T, 2, 1, 4>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
