@@ -151,19 +151,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                         const int kh = tap / 3, kw = tap % 3;
                         if (sidx + 1 < NSTEP) wstore((sidx + 1) % 3);
                         if (sidx + 2 < NSTEP) wload(sidx + 2);
+                        int sw = ((sw_row + kh) & 1) << 1;
+                        if (SPF == 8) sw |= (((sw_col + 2 * kh + kw) >> 1) & 1) << 2;
+                        if (SPF >= 16) sw |= ((sw_col + 2 * kh + kw) & 3) << 2;
+                        const T* bptr = halo + lane_el + (kh * HW_ + kw) * CK + (((chunk * 4 + q) ^ sw) << 3);
+                        // the halo image is static: the first half of this tap's patch fragments is requested before the
+                        // barrier that publishes the weight slice, so the LDS latency overlaps the barrier wait
+                        constexpr int PRE = CK == 64 ? 0 : MT / 2;         // the CK=64 variants have no registers to spare
+                        Frag<T> bpre[PRE > 0 ? PRE : 1];
+#pragma unroll
+                        for (int m = 0; m < PRE; ++m) frag_load(bpre[m], bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
                         __syncthreads();
                         Frag<T> a[NT];
                         const T* aslot = wring + (sidx % 3) * WSLOT;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) frag_load(a[t], aslot + aoff[t]);
-                        int sw = ((sw_row + kh) & 1) << 1;
-                        if (SPF == 8) sw |= (((sw_col + 2 * kh + kw) >> 1) & 1) << 2;
-                        if (SPF >= 16) sw |= ((sw_col + 2 * kh + kw) & 3) << 2;
-                        const T* bptr = halo + lane_el + (kh * HW_ + kw) * CK + (((chunk * 4 + q) ^ sw) << 3);
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             Frag<T> b;
-                            frag_load(b, bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
+                            if (m < PRE) b = bpre[m];
+                            else frag_load(b, bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
 #pragma unroll
                             for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a[t], b, acc[m][t]);
                         }
