@@ -441,6 +441,9 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const float* __restr
 }
 
 constexpr int MAX_STAT_PARTIALS = 512;
+}  // namespace
+int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st);   // conv_v2.hip
+namespace {
 
 template <typename T, int NT, int CB, int PG, int CK, bool WLDS = false>
 int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int N, int H, int W, int Cip, int Cop, hipStream_t st) {
@@ -522,6 +525,25 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
         return 0;
     }
     HYB_CHECK_ARG(Cip % 32 == 0);
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the asynchronous kernel (conv_v2.hip) takes every shape it has a variant for; HYB_CONV_V2=0 keeps the first-generation kernel
+        static const int v2 = getenv("HYB_CONV_V2") ? atoi(getenv("HYB_CONV_V2")) : 1;
+        if (v2) {
+            const int rows = part ? hyb_conv_stats_rows(0, N, H, W, Cop) : 0;
+            HybProfileHook* hook = hyb_find_hook(1, Cip, Cop);
+            if (hook) hipEventRecord(hook->ev0, st);
+            const int rc = hyb_conv_v2(x, wp, y, part, N, H, W, Cip, Cop, rows, st);
+            if (rc != -100) {
+                if (hook) hipEventRecord(hook->ev1, st);
+                if (rc) return rc;
+                if (part && stats) {
+                    hipLaunchKernelGGL(stats_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, stats, rows, 2 * Cop);
+                    HYB_LAUNCH_CHECK();
+                }
+                return 0;
+            }
+        }
+    }
     static const int cfg = getenv("HYB_CONV_CFG") ? atoi(getenv("HYB_CONV_CFG")) : 0;
     if (cfg != 2 && Cop % 256 == 0) return launch_conv<T, 4, 4, 1>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);
     if (Cop % 128 == 0) return launch_conv<T, 4, 2, 2>((const T*)x, (const T*)wp, (T*)y, stats, part, N, H, W, Cip, Cop, st);

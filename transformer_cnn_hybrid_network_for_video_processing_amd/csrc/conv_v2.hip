@@ -1,0 +1,358 @@
+// conv3x3 (stride 1, zero pad 1), bf16, NHWC: the asynchronous implicit-GEMM kernel used for forward (nn.Conv2d of
+// UNet.py:58) and dgrad (mode-1 packed weights) whenever the channel counts allow it.
+//
+// One 512-thread workgroup per CU (8 waves = CB channel blocks x PGR x PGC pixel groups), persistent over image tiles.
+//   * a wave owns a strip of 7 patches (4 x 28 pixels) x NT*16 output channels: 28 | 224/2^k, so the stages of a 224 x 224
+//     clip tile without remainder in x;
+//   * the input halo of a 32-channel block and the per-tap weight slices never pass through registers: both are written
+//     into LDS by global_load_lds_dwordx4 (LDS-DMA).  Halo images are double buffered, weight slices live in a ring of R
+//     slots, so the loads of block j+1 / step s+R-1 are in flight while block j / step s is on the matrix cores;
+//   * every wave issues the same, compile-time-known number of DMA instructions per step, which makes the only
+//     synchronisation of a step one counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` (no vmcnt(0) in the loop);
+//   * the A fragments of step s+1 and the patch fragments of step s+1 are read from LDS during the MFMAs of step s;
+//   * output channels are permuted inside the MFMA tiles so that a lane ends up with 8 consecutive channels per 32-channel
+//     half: an epilogue store instruction writes 64 contiguous bytes per pixel;
+//   * the BatchNorm batch statistics (UNet.py:59) are folded into the epilogue from the fp32 accumulators, reduced in a fixed
+//     order (bit-reproducible).
+#include <stdlib.h>
+#include <type_traits>
+#include "hyb_common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];    // source of every out-of-image halo fragment
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void dma16(const bf16* src, bf16* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds(src, (lds_void_t*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int S> using step_c = std::integral_constant<int, S>;
+
+template <int NT, int CB, int PGR, int PGC, int R>
+struct V2Geom {
+    static constexpr int PG = PGR * PGC, MT = 7;
+    static constexpr int TH = 4 * PGR, TW = 28 * PGC, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
+    static constexpr int NHW = (HP * 4 + 63) / 64;          // halo wave-instructions (64 x 16 B each)
+    static constexpr int HT = (NHW + 7) / 8;                // ... per wave
+    static constexpr int HBUF = NHW * 512;                  // bf16 elements per halo buffer
+    static constexpr int CBW = CB * NT * 16;                // output channels per workgroup
+    static constexpr int WSLOT = CBW * 32;                  // bf16 elements per ring slot
+    static constexpr int NWW = CBW / 16;                    // weight wave-instructions per slice
+    static constexpr int WI = NWW >= 8 ? NWW / 8 : 1;       // ... per wave (duplicated when the slice is smaller than 8 KiB)
+    static constexpr int NHS = 10 - R;                      // halo pieces are issued in steps 0 .. NHS-1 (see wait rule)
+    static constexpr int STAT_FLOATS = 8 * 2 * NT * 16;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * HBUF + R * WSLOT) * 2 + STAT_FLOATS * 4;
+    static_assert(CB * PG == 8, "eight waves");
+    static_assert(HW_ % 4 == 2, "halo swizzle assumes halo width = 2 mod 4");
+    static_assert(R >= 3 && R <= 6, "ring depth");
+    // halo pieces of step s
+    static constexpr int hi(int s) { s = ((s % 9) + 9) % 9; return s < NHS ? (HT + NHS - 1 - s) / NHS : 0; }
+    static constexpr int hstart(int s) { int a = 0; for (int j = 0; j < s; ++j) a += hi(j); return a; }
+    // DMA instructions younger than the weights of step s+2 when step s ends (= the vmcnt to wait for)
+    static constexpr int wait_n(int s) {
+        int n = hi(s - R + 3);
+        for (int j = s - R + 4; j <= s; ++j) n += WI + hi(j);
+        return n;
+    }
+};
+
+template <int NT, int CB, int PGR, int PGC, int R, bool STATS>
+__global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+                                                            bf16* __restrict__ y, float* __restrict__ stats,
+                                                            int N, int H, int W, int Cip, int Cop,
+                                                            int tilesX, int tilesY, int numTiles, int stat_rows) {
+    using G = V2Geom<NT, CB, PGR, PGC, R>;
+    constexpr int MT = G::MT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, HT = G::HT, NHW = G::NHW;
+    constexpr int CBW = G::CBW, WSLOT = G::WSLOT, NWW = G::NWW, WI = G::WI, PG = G::PG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* const hbuf = reinterpret_cast<bf16*>(smem_raw);                       // [2][HBUF]
+    bf16* const wring = hbuf + 2 * G::HBUF;                                     // [R][WSLOT]
+    float* const wgstat = reinterpret_cast<float*>(wring + R * WSLOT);          // [8 waves][2][NT*16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % CB, pg = wave / CB;
+    const int prow = pg / PGC, pstrip = pg % PGC;
+    const int p = lane & 15, q = lane >> 4, py = p >> 2, px = p & 3;
+    const int co_wg = blockIdx.y * CBW;
+    const int co_base = co_wg + cb * (NT * 16);
+    const int nCblk = Cip / 32;
+    const long long wrow = (long long)9 * Cip;                                  // packed row: [Cip/32][9][32]
+    const long long zdiff = reinterpret_cast<const char*>(g_zero_page) - reinterpret_cast<const char*>(x);
+
+    if (STATS) {
+        for (int i = tid; i < G::STAT_FLOATS; i += 512) wgstat[i] = 0.f;
+    }
+
+    // ---- halo DMA pieces of this lane: element offset from the halo origin pixel and (hy, hx)
+    int hoff[HT], hyx[HT], hdst[HT];
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        int wi = k * 8 + wave;
+        if (wi > NHW - 1) wi = NHW - 1;                                         // duplicate the last piece: equal counts per wave
+        const int u = wi * 64 + lane, hp = u >> 2, sp = u & 3;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int s = sp ^ ((hy & 1) << 1);                                     // halo swizzle for 32-channel pixels
+        hoff[k] = (hy * W + hx) * Cip + s * 8;
+        hyx[k] = hp < HP ? ((hy << 16) | hx) : (0x7fff << 16);
+        hdst[k] = wi * 512;
+    }
+    // ---- weight DMA pieces of this lane
+    const bf16* wsrc[WI];
+    int wdst[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int wi = (i * 8 + wave) % NWW;
+        const int u = wi * 64 + lane, row = u >> 2, sp = u & 3;
+        const int f = (4 - ((row >> 3) & 3)) & 3;
+        wsrc[i] = wp + (long long)(co_wg + row) * wrow + ((sp ^ f) << 3);
+        wdst[i] = wi * 512;
+    }
+    // ---- fragment addresses.  Row (t, p) of the MFMA tile holds channel (t>>1)*32 + (p>>2)*8 + (t&1)*4 + (p&3).
+    int aoff[NT];
+    {
+        const int akey = (4 - (p >> 2)) & 3;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            aoff[t] = (cb * (NT * 16) + (t >> 1) * 32 + (p >> 2) * 8 + (t & 1) * 4 + (p & 3)) * 32 + ((q ^ akey) << 3);
+    }
+    const int lane_el = ((prow * 4 + py) * HW_ + pstrip * 28 + px) * 32;
+
+    // block descriptors (wave-uniform)
+    struct Blk { int n, ty0, tx0, cblk; };
+    auto decode = [&](int tile, int cblk) {
+        Blk b;
+        b.n = tile / (tilesX * tilesY);
+        const int trem = tile - b.n * (tilesX * tilesY);
+        b.ty0 = (trem / tilesX) * TH;
+        b.tx0 = (trem % tilesX) * TW;
+        b.cblk = cblk;
+        return b;
+    };
+    auto halo_piece = [&](const Blk& b, bf16* hb, int k) {
+        const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * Cip + b.cblk * 32;
+        const int gy = b.ty0 - 1 + (hyx[k] >> 16), gx = b.tx0 - 1 + (hyx[k] & 0xffff);
+        const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+        const long long boff = valid ? (base + hoff[k]) * 2 : zdiff;          // a select, not a branch: keeps the step one scheduling region
+        dma16(reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(x) + boff), hb + hdst[k]);
+    };
+    auto weight_pieces = [&](int cblk, int tap, int slot) {
+        const int so = (cblk * 9 + tap) * 32;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) dma16(wsrc[i] + so, wring + slot * WSLOT + wdst[i]);
+    };
+    auto bptr_of = [&](const bf16* hb, int tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int sw = ((py + kh) & 1) << 1;
+        return hb + lane_el + (kh * HW_ + kw) * 32 + ((q ^ sw) << 3);
+    };
+
+    int tile = blockIdx.x;
+    Blk cur = decode(tile, 0);
+    int hsel = 0, slot_cur = 0;
+
+    // ---- prologue: halo of the first block, weights of steps 0 .. R-2
+#pragma unroll
+    for (int k = 0; k < HT; ++k) halo_piece(cur, hbuf, k);
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) weight_pieces(0, s, s);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    Frag<bf16> a_cur[NT], bfr[MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) frag_load(a_cur[t], wring + aoff[t]);
+    {
+        const bf16* bp = bptr_of(hbuf, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) frag_load(bfr[m], bp + m * 128);
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    while (true) {
+        // next block: the following channel block of this tile, else the first block of this workgroup's next tile
+        const bool last_cblk = cur.cblk + 1 >= nCblk;
+        const int ntile = last_cblk ? (tile + (int)gridDim.x < numTiles ? tile + (int)gridDim.x : tile) : tile;
+        const Blk nxt = decode(ntile, last_cblk ? 0 : cur.cblk + 1);
+        bf16* const hb_cur = hbuf + hsel * G::HBUF;
+        bf16* const hb_nxt = hbuf + (hsel ^ 1) * G::HBUF;
+
+        auto step = [&](auto S_) __attribute__((always_inline)) {
+            constexpr int S = decltype(S_)::value;
+            // (1) DMA: weights of step S+R-1 into the slot freed by step S-1, then this step's share of the next halo
+            {
+                constexpr int FT = (S + R - 1) % 9;
+                const int fc = (S + R - 1 >= 9) ? nxt.cblk : cur.cblk;
+                int slot_fill = slot_cur - 1;
+                if (slot_fill < 0) slot_fill += R;
+                weight_pieces(fc, FT, slot_fill);
+#pragma unroll
+                for (int k = 0; k < G::hi(S); ++k) halo_piece(nxt, hb_nxt, G::hstart(S) + k);
+            }
+            // (2) A fragments of step S+1 (their slot was published by the barrier that ended step S-1)
+            int slot_next = slot_cur + 1;
+            if (slot_next >= R) slot_next -= R;
+            Frag<bf16> a_nxt[NT];
+            {
+                const bf16* as = wring + slot_next * WSLOT;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) frag_load(a_nxt[t], as + aoff[t]);
+            }
+            // (3) MFMAs of step S; each patch fragment is replaced by the one step S+1 needs as soon as it has been used
+            const bf16* bp = bptr_of(S == 8 ? hb_nxt : hb_cur, (S + 1) % 9);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a_cur[t], bfr[m], acc[m][t]);
+                frag_load(bfr[m], bp + m * 128);
+            }
+            // pin the interleave: the LDS reads of step S+1 trickle out between the MFMA groups of step S
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                      // MFMA
+                if (m < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);           // DS read (A of S+1 first, then patches)
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+            slot_cur = slot_next;
+            // (4) the weights of step S+2 (and everything older) have landed for this wave; publish
+            wait_vmcnt<G::wait_n(S)>();
+            __builtin_amdgcn_s_barrier();
+        };
+        step(step_c<0>{}); step(step_c<1>{}); step(step_c<2>{}); step(step_c<3>{}); step(step_c<4>{});
+        step(step_c<5>{}); step(step_c<6>{}); step(step_c<7>{}); step(step_c<8>{});
+
+        if (last_cblk) {
+            // ---- epilogue: the lane holds 8 consecutive channels per 32-channel half of one pixel per patch
+            const int n = cur.n, ty0 = cur.ty0, tx0 = cur.tx0;
+            const bool full = (ty0 + TH <= H) && (tx0 + TW <= W);
+            float s1[NT][4], s2[NT][4];
+            if (STATS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+            }
+            const int gy = ty0 + prow * 4 + py;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gx = tx0 + pstrip * 28 + m * 4 + px;
+                const bool valid = full || ((gy < H) && (gx < W));
+                if (valid) {
+                    bf16* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * 8;
+#pragma unroll
+                    for (int h = 0; h < (NT + 1) / 2; ++h) {
+                        Vec8<bf16> v;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v.set(j, acc[m][NT == 1 ? 0 : h * 2 + (j >> 2)][j & 3]);
+                        v.store(dst + h * 32);
+                    }
+                    if (STATS) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[m][t][r];
+                                s1[t][r] += v;
+                                s2[t][r] = fmaf(v, v, s2[t][r]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (STATS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
+                        if (p == 0) {
+                            const int cl = (t >> 1) * 32 + q * 8 + (t & 1) * 4 + r;
+                            wgstat[(wave * 2 + 0) * (NT * 16) + cl] += a;
+                            wgstat[(wave * 2 + 1) * (NT * 16) + cl] += b;
+                        }
+                    }
+            }
+            if (tile + (int)gridDim.x >= numTiles) break;
+            tile += gridDim.x;
+        }
+        cur = nxt;
+        hsel ^= 1;
+    }
+
+    wait_vmcnt<0>();                 // the run-ahead DMA of the (non-existent) next block must not outlive the workgroup
+    if (STATS) {
+        __syncthreads();
+        for (int i = tid; i < 2 * CBW; i += 512) {
+            const int which = i / CBW, cl = i % CBW;
+            const int cbi = cl / (NT * 16), c16 = cl % (NT * 16);
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) a += wgstat[((g * CB + cbi) * 2 + which) * (NT * 16) + c16];     // wave = pg*CB + cb
+            stats[((long long)blockIdx.x * 2 + which) * Cop + co_wg + cl] = a;
+            // the caller sums a fixed number of partial rows: rows no workgroup owns are zero
+            for (int rrow = blockIdx.x + gridDim.x; rrow < stat_rows; rrow += gridDim.x) stats[((long long)rrow * 2 + which) * Cop + co_wg + cl] = 0.f;
+        }
+    }
+}
+
+template <int NT, int CB, int PGR, int PGC, int R>
+int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st) {
+    using G = V2Geom<NT, CB, PGR, PGC, R>;
+    const int tilesX = hyb_cdiv(W, G::TW), tilesY = hyb_cdiv(H, G::TH);
+    const long long numTiles = (long long)N * tilesX * tilesY;
+    int gx = (int)(numTiles < 256 ? numTiles : 256);
+    if (part && gx > stat_rows) gx = stat_rows;
+    if (gx < 1) gx = 1;
+    const dim3 grid(gx, Cop / G::CBW);
+    const void* f = part ? (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true> : (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>;
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    if (part)
+        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>), grid, dim3(512), G::LDS_BYTES, st, x, wp, y, part, N, H, W, Cip, Cop,
+                           tilesX, tilesY, (int)numTiles, stat_rows);
+    else
+        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>), grid, dim3(512), G::LDS_BYTES, st, x, wp, y, (float*)nullptr, N, H, W,
+                           Cip, Cop, tilesX, tilesY, (int)numTiles, 0);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// relative cost of covering an H x W image with TH x TW tiles on 256 persistent workgroups
+double v2_cost(int N, int H, int W, int TH, int TW, int gy) {
+    const long long tiles = (long long)N * hyb_cdiv(W, TW) * hyb_cdiv(H, TH) * gy;
+    const long long rounds = (tiles + 255) / 256;
+    return (double)rounds * TH * TW;
+}
+
+}  // namespace
+
+// Internal (conv_fwd.hip): returns -100 when no asynchronous variant fits this shape.  part: partial-statistics rows
+// [stat_rows][2][Cop] (may be NULL), all of them written.
+int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st) {
+    if (Cip % 32 != 0 || (long long)40 * W * Cip >= (1ll << 31)) return -100;          // per-lane halo offsets are 32-bit
+    const bf16* xb = (const bf16*)x; const bf16* wb = (const bf16*)wp; bf16* yb = (bf16*)y;
+#define V2(NT_, CB_, PGR_, PGC_, R_) launch_v2<NT_, CB_, PGR_, PGC_, R_>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st)
+    if (Cop % 256 == 0) {
+        return v2_cost(N, H, W, 8, 28, Cop / 256) <= v2_cost(N, H, W, 4, 56, Cop / 256) ? V2(4, 4, 2, 1, 4) : V2(4, 4, 1, 2, 4);
+    }
+    if (Cop % 128 == 0) {
+        return v2_cost(N, H, W, 16, 28, Cop / 128) <= v2_cost(N, H, W, 8, 56, Cop / 128) ? V2(4, 2, 4, 1, 4) : V2(4, 2, 2, 2, 4);
+    }
+    if (Cop % 64 == 0) return V2(4, 1, 4, 2, 4);
+    if (Cop % 32 == 0) return V2(2, 1, 4, 2, 4);
+#undef V2
+    return -100;
+}
