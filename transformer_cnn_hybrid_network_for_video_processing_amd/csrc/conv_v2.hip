@@ -47,6 +47,7 @@ struct V2Geom {
     static constexpr int STAT_FLOATS = 8 * 2 * NT * 16;
     static constexpr size_t LDS_BYTES = (size_t)(2 * HBUF + R * WSLOT) * 2 + STAT_FLOATS * 4;
     static_assert(CB * PG == 8, "eight waves");
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
     static_assert(HW_ % 4 == 2, "halo swizzle assumes halo width = 2 mod 4");
     static_assert(R >= 3 && R <= 6, "ring depth");
     // halo pieces of step s
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
     int tile = blockIdx.x;
     Blk cur = decode(tile, 0);
     int hsel = 0, slot_cur = 0;
+    bool after_store = false;                       // the previous block ended with a full-tile epilogue (NS stores per wave)
+    constexpr int NS = MT * ((NT + 1) / 2);
 
     // ---- prologue: halo of the first block, weights of steps 0 .. R-2
 #pragma unroll
@@ -227,7 +230,13 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
             for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
             slot_cur = slot_next;
             // (4) the weights of step S+2 (and everything older) have landed for this wave; publish
-            wait_vmcnt<G::wait_n(S)>();
+            //     After a full-tile epilogue the NS output stores are younger than the weights waited for in the first R-3 steps
+            //     (those were issued before the epilogue): counting them keeps the stores in flight instead of draining them.
+            if constexpr (S < R - 3) {
+                if (after_store) wait_vmcnt<G::wait_n(S) + NS>(); else wait_vmcnt<G::wait_n(S)>();
+            } else {
+                wait_vmcnt<G::wait_n(S)>();
+            }
             __builtin_amdgcn_s_barrier();
         };
         step(step_c<0>{}); step(step_c<1>{}); step(step_c<2>{}); step(step_c<3>{}); step(step_c<4>{});
@@ -245,39 +254,50 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
                     for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
             }
             const int gy = ty0 + prow * 4 + py;
+            auto emit = [&](auto FULL_) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(FULL_)::value;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int gx = tx0 + pstrip * 28 + m * 4 + px;
-                const bool valid = full || ((gy < H) && (gx < W));
-                if (valid) {
-                    bf16* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * 8;
+                for (int m = 0; m < MT; ++m) {
+                    const int gx = tx0 + pstrip * 28 + m * 4 + px;
+                    const bool valid = FULL || ((gy < H) && (gx < W));
+                    if (valid) {
+                        bf16* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * 8;
 #pragma unroll
-                    for (int h = 0; h < (NT + 1) / 2; ++h) {
-                        Vec8<bf16> v;
+                        for (int h = 0; h < (NT + 1) / 2; ++h) {
+                            Vec8<bf16> v;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v.set(j, acc[m][NT == 1 ? 0 : h * 2 + (j >> 2)][j & 3]);
-                        v.store(dst + h * 32);
+                            for (int j = 0; j < 8; ++j) v.set(j, acc[m][NT == 1 ? 0 : h * 2 + (j >> 2)][j & 3]);
+                            v.store(dst + h * 32);
+                        }
+                        if (STATS) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = acc[m][t][r];
+                                    s1[t][r] += v;
+                                    s2[t][r] = fmaf(v, v, s2[t][r]);
+                                }
+                        }
                     }
-                    if (STATS) {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[m][t][r];
-                                s1[t][r] += v;
-                                s2[t][r] = fmaf(v, v, s2[t][r]);
-                            }
-                    }
+                    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            if (full) {
+                emit(std::true_type{});          // exactly NS store instructions per wave: the next waits step over them by count
+                after_store = true;
+            } else {
+                emit(std::false_type{});         // edge tile: the store count depends on the lane masks, so drain instead
+                wait_vmcnt<0>();
+                after_store = false;
             }
             if (STATS) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float a = group16_sum(s1[t][r]), b = group16_sum(s2[t][r]);
+                        const float a = row16_sum(s1[t][r]), b = row16_sum(s2[t][r]);
                         if (p == 0) {
                             const int cl = (t >> 1) * 32 + q * 8 + (t & 1) * 4 + r;
                             wgstat[(wave * 2 + 0) * (NT * 16) + cl] += a;
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
             if (tile + (int)gridDim.x >= numTiles) break;
             tile += gridDim.x;
         }
+        else after_store = false;
         cur = nxt;
         hsel ^= 1;
     }
@@ -346,13 +367,13 @@ int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int 
     const bf16* xb = (const bf16*)x; const bf16* wb = (const bf16*)wp; bf16* yb = (bf16*)y;
 #define V2(NT_, CB_, PGR_, PGC_, R_) launch_v2<NT_, CB_, PGR_, PGC_, R_>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st)
     if (Cop % 256 == 0) {
-        return v2_cost(N, H, W, 8, 28, Cop / 256) <= v2_cost(N, H, W, 4, 56, Cop / 256) ? V2(4, 4, 2, 1, 4) : V2(4, 4, 1, 2, 4);
+        return v2_cost(N, H, W, 8, 28, Cop / 256) <= v2_cost(N, H, W, 4, 56, Cop / 256) ? V2(4, 4, 2, 1, 6) : V2(4, 4, 1, 2, 6);
     }
     if (Cop % 128 == 0) {
-        return v2_cost(N, H, W, 16, 28, Cop / 128) <= v2_cost(N, H, W, 8, 56, Cop / 128) ? V2(4, 2, 4, 1, 4) : V2(4, 2, 2, 2, 4);
+        return v2_cost(N, H, W, 16, 28, Cop / 128) <= v2_cost(N, H, W, 8, 56, Cop / 128) ? V2(4, 2, 4, 1, 6) : V2(4, 2, 2, 2, 6);
     }
-    if (Cop % 64 == 0) return V2(4, 1, 4, 2, 4);
-    if (Cop % 32 == 0) return V2(2, 1, 4, 2, 4);
+    if (Cop % 64 == 0) return V2(4, 1, 4, 2, 5);
+    if (Cop % 32 == 0) return V2(2, 1, 4, 2, 6);
 #undef V2
     return -100;
 }

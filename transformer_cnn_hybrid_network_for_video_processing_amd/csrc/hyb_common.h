@@ -126,6 +126,19 @@ __device__ __forceinline__ float group16_sum(float v) {
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// same sum over the 16 lanes of a DPP row, but with row rotations (v_add_f32_dpp, no LDS crossbar): every lane of the row
+// ends up with the total.  The order of the additions differs from group16_sum (both are fixed orders).
+template <int CTRL> __device__ __forceinline__ float dpp_rot_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_rot_add<0x128>(v);      // row_ror:8
+    v = dpp_rot_add<0x124>(v);      // row_ror:4
+    v = dpp_rot_add<0x122>(v);      // row_ror:2
+    v = dpp_rot_add<0x121>(v);      // row_ror:1
+    return v;
+}
 __device__ __forceinline__ float group16_max(float v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
