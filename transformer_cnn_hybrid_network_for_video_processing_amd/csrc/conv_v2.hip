@@ -1,15 +1,19 @@
 // conv3x3 (stride 1, zero pad 1), bf16, NHWC: the asynchronous implicit-GEMM kernel used for forward (nn.Conv2d of
 // UNet.py:58) and dgrad (mode-1 packed weights) whenever the channel counts allow it.
 //
-// One 512-thread workgroup per CU (8 waves = CB channel blocks x PGR x PGC pixel groups), persistent over image tiles.
+// A workgroup is NW = CB x PGR x PGC waves (CB channel blocks x pixel groups), persistent over image tiles: either one
+// 8-wave workgroup per CU (all 160 KiB of LDS: deep weight ring for 256-channel blocks) or two independent 4-wave workgroups
+// per CU, whose epilogues (vector work) and MFMA phases interleave on the SIMDs.
 //   * a wave owns a strip of 7 patches (4 x 28 pixels) x NT*16 output channels: 28 | 224/2^k, so the stages of a 224 x 224
 //     clip tile without remainder in x;
 //   * the input halo of a 32-channel block and the per-tap weight slices never pass through registers: both are written
-//     into LDS by global_load_lds_dwordx4 (LDS-DMA).  Halo images are double buffered, weight slices live in a ring of R
-//     slots, so the loads of block j+1 / step s+R-1 are in flight while block j / step s is on the matrix cores;
+//     into LDS by buffer_load_dwordx4 ... lds (LDS-DMA).  Out-of-image halo lanes are sent out of the descriptor's range and
+//     the hardware writes zeros for them (the zero padding costs no branch).  Halo images are double buffered, weight slices
+//     live in a ring of R slots, so the loads of block j+1 / step s+R-1 are in flight while block j / step s is computed;
 //   * every wave issues the same, compile-time-known number of DMA instructions per step, which makes the only
-//     synchronisation of a step one counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` (no vmcnt(0) in the loop);
-//   * the A fragments of step s+1 and the patch fragments of step s+1 are read from LDS during the MFMAs of step s;
+//     synchronisation of a step one counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` (no vmcnt(0) in the loop); after a
+//     full-tile epilogue the count also steps over that tile's output stores, which stay in flight;
+//   * the A fragments and the patch fragments of step s+1 are read from LDS between the MFMA groups of step s;
 //   * output channels are permuted inside the MFMA tiles so that a lane ends up with 8 consecutive channels per 32-channel
 //     half: an epilogue store instruction writes 64 contiguous bytes per pixel;
 //   * the BatchNorm batch statistics (UNet.py:59) are folded into the epilogue from the fp32 accumulators, reduced in a fixed
@@ -20,34 +24,38 @@
 
 namespace {
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];    // source of every out-of-image halo fragment
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ void dma16(const bf16* src, bf16* lds_dst_wave_base) {
-    __builtin_amdgcn_global_load_lds(src, (lds_void_t*)lds_dst_wave_base, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane through a buffer descriptor: LDS destination = wave-uniform base + lane * 16, source =
+// descriptor base + voff + soff.  A lane whose voff is outside the descriptor's range writes ZEROS (measured on gfx950):
+// that is how the out-of-image part of a halo gets its zero padding, without a branch or a zero page.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, bf16* lds_dst_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_dst_wave_base, 16, voff, soff, 0, 0);
 }
+constexpr unsigned V2_OOB = 0xfffffff0u;        // beyond every descriptor below (num_records = 2^31)
+constexpr unsigned V2_RECORDS = 0x80000000u;
 
 template <int S> using step_c = std::integral_constant<int, S>;
 
 template <int NT, int CB, int PGR, int PGC, int R>
 struct V2Geom {
     static constexpr int PG = PGR * PGC, MT = 7;
+    static constexpr int NW = CB * PG;                       // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
     static constexpr int TH = 4 * PGR, TW = 28 * PGC, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
     static constexpr int NHW = (HP * 4 + 63) / 64;          // halo wave-instructions (64 x 16 B each)
-    static constexpr int HT = (NHW + 7) / 8;                // ... per wave
+    static constexpr int HT = (NHW + NW - 1) / NW;          // ... per wave
     static constexpr int HBUF = NHW * 512;                  // bf16 elements per halo buffer
     static constexpr int CBW = CB * NT * 16;                // output channels per workgroup
     static constexpr int WSLOT = CBW * 32;                  // bf16 elements per ring slot
     static constexpr int NWW = CBW / 16;                    // weight wave-instructions per slice
-    static constexpr int WI = NWW >= 8 ? NWW / 8 : 1;       // ... per wave (duplicated when the slice is smaller than 8 KiB)
+    static constexpr int WI = NWW >= NW ? NWW / NW : 1;     // ... per wave (duplicated when the slice has fewer pieces than waves)
     static constexpr int NHS = 10 - R;                      // halo pieces are issued in steps 0 .. NHS-1 (see wait rule)
-    static constexpr int STAT_FLOATS = 8 * 2 * NT * 16;
+    static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr size_t LDS_BYTES = (size_t)(2 * HBUF + R * WSLOT) * 2 + STAT_FLOATS * 4;
-    static_assert(CB * PG == 8, "eight waves");
-    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
+    static_assert(NW == 8 || NW == 4, "four or eight waves");
+    static_assert(LDS_BYTES <= (NW == 8 ? 160 : 80) * 1024, "160 KiB of LDS per CU");
     static_assert(HW_ % 4 == 2, "halo swizzle assumes halo width = 2 mod 4");
     static_assert(R >= 3 && R <= 6, "ring depth");
     // halo pieces of step s
@@ -62,17 +70,17 @@ struct V2Geom {
 };
 
 template <int NT, int CB, int PGR, int PGC, int R, bool STATS>
-__global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
+__global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) void conv3x3_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                             bf16* __restrict__ y, float* __restrict__ stats,
                                                             int N, int H, int W, int Cip, int Cop,
                                                             int tilesX, int tilesY, int numTiles, int stat_rows) {
     using G = V2Geom<NT, CB, PGR, PGC, R>;
     constexpr int MT = G::MT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, HT = G::HT, NHW = G::NHW;
-    constexpr int CBW = G::CBW, WSLOT = G::WSLOT, NWW = G::NWW, WI = G::WI, PG = G::PG;
+    constexpr int CBW = G::CBW, WSLOT = G::WSLOT, NWW = G::NWW, WI = G::WI, PG = G::PG, NW = G::NW, NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* const hbuf = reinterpret_cast<bf16*>(smem_raw);                       // [2][HBUF]
     bf16* const wring = hbuf + 2 * G::HBUF;                                     // [R][WSLOT]
-    float* const wgstat = reinterpret_cast<float*>(wring + R * WSLOT);          // [8 waves][2][NT*16]
+    float* const wgstat = reinterpret_cast<float*>(wring + R * WSLOT);          // [NW waves][2][NT*16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,44 +92,40 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
     const int co_base = co_wg + cb * (NT * 16);
     const int nCblk = Cip / 32;
     const long long wrow = (long long)9 * Cip;                                  // packed row: [Cip/32][9][32]
-    const long long zdiff = reinterpret_cast<const char*>(g_zero_page) - reinterpret_cast<const char*>(x);
 
     if (STATS) {
-        for (int i = tid; i < G::STAT_FLOATS; i += 512) wgstat[i] = 0.f;
+        for (int i = tid; i < G::STAT_FLOATS; i += NTHR) wgstat[i] = 0.f;
     }
 
-    // ---- halo DMA pieces of this lane: element offset from the halo origin pixel and (hy, hx)
-    int hoff[HT], hyx[HT], hdst[HT];
+    // ---- halo DMA pieces of this lane: byte offset from the halo origin pixel, and (hy, hx) for the bounds test
+    constexpr bool HOFF_REG = true;              // large halos: recompute the offset per piece instead of holding it (registers)
+    unsigned hoff[HOFF_REG ? HT : 1];
+    int hyx[HT];
 #pragma unroll
     for (int k = 0; k < HT; ++k) {
-        int wi = k * 8 + wave;
+        int wi = k * NW + wave;
         if (wi > NHW - 1) wi = NHW - 1;                                         // duplicate the last piece: equal counts per wave
         const int u = wi * 64 + lane, hp = u >> 2, sp = u & 3;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int s = sp ^ ((hy & 1) << 1);                                     // halo swizzle for 32-channel pixels
-        hoff[k] = (hy * W + hx) * Cip + s * 8;
-        hyx[k] = hp < HP ? ((hy << 16) | hx) : (0x7fff << 16);
-        hdst[k] = wi * 512;
+        if (HOFF_REG) hoff[k] = (unsigned)(((hy * W + hx) * Cip + s * 8) * 2);
+        hyx[k] = hp < HP ? ((hy << 20) | (hx << 4) | s) : (0x7ff << 20);
     }
-    // ---- weight DMA pieces of this lane
-    const bf16* wsrc[WI];
+    // ---- weight DMA pieces of this lane: byte offset inside this workgroup's CBW packed rows
+    unsigned woff[WI];
     int wdst[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int wi = (i * 8 + wave) % NWW;
+        const int wi = (i * NW + wave) % NWW;
         const int u = wi * 64 + lane, row = u >> 2, sp = u & 3;
         const int f = (4 - ((row >> 3) & 3)) & 3;
-        wsrc[i] = wp + (long long)(co_wg + row) * wrow + ((sp ^ f) << 3);
+        woff[i] = (unsigned)(((long long)row * wrow + ((sp ^ f) << 3)) * 2);
         wdst[i] = wi * 512;
     }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(wp + (long long)co_wg * wrow), 0, V2_RECORDS, 0x00020000);
     // ---- fragment addresses.  Row (t, p) of the MFMA tile holds channel (t>>1)*32 + (p>>2)*8 + (t&1)*4 + (p&3).
-    int aoff[NT];
-    {
-        const int akey = (4 - (p >> 2)) & 3;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            aoff[t] = (cb * (NT * 16) + (t >> 1) * 32 + (p >> 2) * 8 + (t & 1) * 4 + (p & 3)) * 32 + ((q ^ akey) << 3);
-    }
+    const int aoff0 = (cb * (NT * 16) + (p >> 2) * 8 + (p & 3)) * 32 + ((q ^ ((4 - (p >> 2)) & 3)) << 3);
+    auto aoff = [&](int t) { return aoff0 + ((t >> 1) * 32 + (t & 1) * 4) * 32; };
     const int lane_el = ((prow * 4 + py) * HW_ + pstrip * 28 + px) * 32;
 
     // block descriptors (wave-uniform)
@@ -135,17 +139,25 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
         b.cblk = cblk;
         return b;
     };
-    auto halo_piece = [&](const Blk& b, bf16* hb, int k) {
+    // descriptor of a block's halo: base = the halo origin pixel (may lie before the tensor for border tiles: such lanes are
+    // sent out of range and never dereference it)
+    auto halo_rsrc = [&](const Blk& b) {
         const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * Cip + b.cblk * 32;
-        const int gy = b.ty0 - 1 + (hyx[k] >> 16), gx = b.tx0 - 1 + (hyx[k] & 0xffff);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(x + base), 0, V2_RECORDS, 0x00020000);
+    };
+    auto halo_piece = [&](const Blk& b, __amdgpu_buffer_rsrc_t rs, bf16* hb, int k) {
+        const int hy = hyx[k] >> 20, hx = (hyx[k] >> 4) & 0xffff;
+        const int gy = b.ty0 - 1 + hy, gx = b.tx0 - 1 + hx;
         const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-        const long long boff = valid ? (base + hoff[k]) * 2 : zdiff;          // a select, not a branch: keeps the step one scheduling region
-        dma16(reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(x) + boff), hb + hdst[k]);
+        const unsigned off = HOFF_REG ? hoff[HOFF_REG ? k : 0] : (unsigned)(((hy * W + hx) * Cip + (hyx[k] & 15) * 8) * 2);
+        int wi = k * NW + wave;
+        if (wi > NHW - 1) wi = NHW - 1;
+        dma16(rs, valid ? off : V2_OOB, 0, hb + wi * 512);
     };
     auto weight_pieces = [&](int cblk, int tap, int slot) {
-        const int so = (cblk * 9 + tap) * 32;
+        const unsigned so = (unsigned)((cblk * 9 + tap) * 64);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) dma16(wsrc[i] + so, wring + slot * WSLOT + wdst[i]);
+        for (int i = 0; i < WI; ++i) dma16(wrsrc, woff[i], so, wring + slot * WSLOT + wdst[i]);
     };
     auto bptr_of = [&](const bf16* hb, int tap) {
         const int kh = tap / 3, kw = tap % 3;
@@ -160,8 +172,11 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
     constexpr int NS = MT * ((NT + 1) / 2);
 
     // ---- prologue: halo of the first block, weights of steps 0 .. R-2
+    {
+        const __amdgpu_buffer_rsrc_t rs0 = halo_rsrc(cur);
 #pragma unroll
-    for (int k = 0; k < HT; ++k) halo_piece(cur, hbuf, k);
+        for (int k = 0; k < HT; ++k) halo_piece(cur, rs0, hbuf, k);
+    }
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) weight_pieces(0, s, s);
     wait_vmcnt<0>();
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
 
     Frag<bf16> a_cur[NT], bfr[MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) frag_load(a_cur[t], wring + aoff[t]);
+    for (int t = 0; t < NT; ++t) frag_load(a_cur[t], wring + aoff(t));
     {
         const bf16* bp = bptr_of(hbuf, 0);
 #pragma unroll
@@ -189,6 +204,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
         const Blk nxt = decode(ntile, last_cblk ? 0 : cur.cblk + 1);
         bf16* const hb_cur = hbuf + hsel * G::HBUF;
         bf16* const hb_nxt = hbuf + (hsel ^ 1) * G::HBUF;
+        const __amdgpu_buffer_rsrc_t nrs = halo_rsrc(nxt);
 
         auto step = [&](auto S_) __attribute__((always_inline)) {
             constexpr int S = decltype(S_)::value;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
                 if (slot_fill < 0) slot_fill += R;
                 weight_pieces(fc, FT, slot_fill);
 #pragma unroll
-                for (int k = 0; k < G::hi(S); ++k) halo_piece(nxt, hb_nxt, G::hstart(S) + k);
+                for (int k = 0; k < G::hi(S); ++k) halo_piece(nxt, nrs, hb_nxt, G::hstart(S) + k);
             }
             // (2) A fragments of step S+1 (their slot was published by the barrier that ended step S-1)
             int slot_next = slot_cur + 1;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
             {
                 const bf16* as = wring + slot_next * WSLOT;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) frag_load(a_nxt[t], as + aoff[t]);
+                for (int t = 0; t < NT; ++t) frag_load(a_nxt[t], as + aoff(t));
             }
             // (3) MFMAs of step S; each patch fragment is replaced by the one step S+1 needs as soon as it has been used
             const bf16* bp = bptr_of(S == 8 ? hb_nxt : hb_cur, (S + 1) % 9);
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(const bf16* __restrict_
     wait_vmcnt<0>();                 // the run-ahead DMA of the (non-existent) next block must not outlive the workgroup
     if (STATS) {
         __syncthreads();
-        for (int i = tid; i < 2 * CBW; i += 512) {
+        for (int i = tid; i < 2 * CBW; i += NTHR) {
             const int which = i / CBW, cl = i % CBW;
             const int cbi = cl / (NT * 16), c16 = cl % (NT * 16);
             float a = 0.f;
@@ -334,7 +350,8 @@ int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H,
     using G = V2Geom<NT, CB, PGR, PGC, R>;
     const int tilesX = hyb_cdiv(W, G::TW), tilesY = hyb_cdiv(H, G::TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
-    int gx = (int)(numTiles < 256 ? numTiles : 256);
+    constexpr int SLOTS = G::NW == 8 ? 256 : 512;           // resident workgroups on 256 CUs
+    int gx = (int)(numTiles < SLOTS ? numTiles : SLOTS);
     if (part && gx > stat_rows) gx = stat_rows;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, Cop / G::CBW);
@@ -342,10 +359,10 @@ int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H,
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     if (part)
-        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>), grid, dim3(512), G::LDS_BYTES, st, x, wp, y, part, N, H, W, Cip, Cop,
+        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>), grid, dim3(G::NW * 64), G::LDS_BYTES, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles, stat_rows);
     else
-        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>), grid, dim3(512), G::LDS_BYTES, st, x, wp, y, (float*)nullptr, N, H, W,
+        hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>), grid, dim3(G::NW * 64), G::LDS_BYTES, st, x, wp, y, (float*)nullptr, N, H, W,
                            Cip, Cop, tilesX, tilesY, (int)numTiles, 0);
     HYB_LAUNCH_CHECK();
     return 0;
@@ -363,9 +380,20 @@ double v2_cost(int N, int H, int W, int TH, int TW, int gy) {
 // Internal (conv_fwd.hip): returns -100 when no asynchronous variant fits this shape.  part: partial-statistics rows
 // [stat_rows][2][Cop] (may be NULL), all of them written.
 int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st) {
-    if (Cip % 32 != 0 || (long long)40 * W * Cip >= (1ll << 31)) return -100;          // per-lane halo offsets are 32-bit
+    if (Cip % 32 != 0 || (long long)40 * W * Cip >= (1ll << 29) || (long long)256 * 9 * Cip >= (1ll << 29)) return -100;   // 32-bit buffer offsets
     const bf16* xb = (const bf16*)x; const bf16* wb = (const bf16*)wp; bf16* yb = (bf16*)y;
 #define V2(NT_, CB_, PGR_, PGC_, R_) launch_v2<NT_, CB_, PGR_, PGC_, R_>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st)
+    // Measured on the 224 x 224 clip stages: two four-wave workgroups per CU (their epilogues and MFMA phases interleave) win for
+    // Cop <= 128; 256-channel blocks need the whole CU's LDS for a deep weight ring.  HYB_V2_NW=4|8 forces one family.
+    static const int nw_env = getenv("HYB_V2_NW") ? atoi(getenv("HYB_V2_NW")) : 0;
+    const int nw = nw_env ? nw_env : (Cop % 256 == 0 ? 8 : 4);
+    if (nw == 4) {
+        if (Cop % 256 == 0) return V2(4, 4, 1, 1, 3);
+        if (Cop % 128 == 0) return v2_cost(N, H, W, 8, 28, Cop / 128) <= v2_cost(N, H, W, 4, 56, Cop / 128) ? V2(4, 2, 2, 1, 4) : V2(4, 2, 1, 2, 4);
+        if (Cop % 64 == 0) return v2_cost(N, H, W, 8, 28, Cop / 64) <= v2_cost(N, H, W, 4, 56, Cop / 64) ? V2(2, 2, 2, 1, 4) : V2(2, 2, 1, 2, 4);
+        if (Cop % 32 == 0) return V2(2, 1, 4, 1, 4);
+        return -100;
+    }
     if (Cop % 256 == 0) {
         return v2_cost(N, H, W, 8, 28, Cop / 256) <= v2_cost(N, H, W, 4, 56, Cop / 256) ? V2(4, 4, 2, 1, 6) : V2(4, 4, 1, 2, 6);
     }
