@@ -122,7 +122,7 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
         woff[i] = (unsigned)(((long long)row * wrow + ((sp ^ f) << 3)) * 2);
         wdst[i] = wi * 512;
     }
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(wp + (long long)co_wg * wrow), 0, V2_RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = hyb_rsrc((wp + (long long)co_wg * wrow), V2_RECORDS);
     // ---- fragment addresses.  Row (t, p) of the MFMA tile holds channel (t>>1)*32 + (p>>2)*8 + (t&1)*4 + (p&3).
     const int aoff0 = (cb * (NT * 16) + (p >> 2) * 8 + (p & 3)) * 32 + ((q ^ ((4 - (p >> 2)) & 3)) << 3);
     auto aoff = [&](int t) { return aoff0 + ((t >> 1) * 32 + (t & 1) * 4) * 32; };
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
     // sent out of range and never dereference it)
     auto halo_rsrc = [&](const Blk& b) {
         const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * Cip + b.cblk * 32;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(x + base), 0, V2_RECORDS, 0x00020000);
+        return hyb_rsrc((x + base), V2_RECORDS);
     };
     auto halo_piece = [&](const Blk& b, __amdgpu_buffer_rsrc_t rs, bf16* hb, int k) {
         const int hy = hyx[k] >> 20, hx = (hyx[k] >> 4) & 0xffff;

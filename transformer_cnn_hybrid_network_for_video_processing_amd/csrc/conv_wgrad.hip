@@ -9,6 +9,7 @@
 // A workgroup owns one output block (64 co x CIT*16 ci x 9 taps, fp32 accumulators in registers) and
 // walks a strided subset of 8x16-pixel tiles; partial blocks go to fp32 slabs [S][Cop][9][Cip] that a
 // second kernel sums in a fixed order (bitwise reproducible; no float atomics).
+#include <stdlib.h>
 #include "hyb_common.h"
 
 namespace {
@@ -274,6 +275,290 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     dw[((long long)co * Ci + ci) * 9 + tap] = s;
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Second generation (bf16, Cip % 64 == 0, Cop % 64 == 0): one 8-wave workgroup per CU owns a 64 co x 64 ci x 9 tap block and
+// walks 8 x 28-pixel tiles (7 k-steps of 32 pixels; 28 | 224/2^k).  The waves are specialised:
+//   * waves 0-3 (consumers, one per SIMD): the contraction.  Wave = 64 co x 16 ci x 9 taps (36 accumulator tiles); fragments are
+//     transposed reads (ds_read_b64_tr_b16) of the two LDS tile images;
+//   * waves 4-7 (producers, one per SIMD, sharing it with a consumer): fill the OTHER pair of tile images meanwhile.  The x halo
+//     is written by buffer_load ... lds (zero padding = out-of-range lanes, see conv_v2.hip).  FUSE: the gradient tile
+//     (BatchNorm/ReLU/MaxPool backward from y, dpooled and per-channel constants) is computed on the vector units, which are
+//     otherwise idle under the consumers' MFMAs, and its dense copy dyraw is written once for the dgrad conv;  plain: the
+//     gradient tile is DMA'd as well.
+//   * both tile images are double buffered, unpadded and XOR-swizzled per 16-byte chunk (DMA needs lane-linear images; the
+//     swizzle keeps the transposed reads of 4 consecutive pixels x 16 channels bank-conflict free);
+//   * one barrier per tile.
+// -----------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr int W2_TH = 8, W2_TW = 28, W2_HW = 30, W2_HP = 10 * 30, W2_PX = 8 * 28;
+constexpr int W2_XW = (W2_HP * 8 + 63) / 64;          // x-halo DMA wave-instructions (38)
+constexpr int W2_DW = W2_PX * 8 / 64;                 // dy-tile DMA wave-instructions (28)
+constexpr int W2_XBUF = W2_XW * 512, W2_DBUF = W2_PX * 64;        // bf16 elements per buffer
+constexpr size_t W2_LDS = (size_t)2 * (W2_XBUF + W2_DBUF) * 2 + 5 * 64 * sizeof(float);
+constexpr unsigned W2_OOB = 0xfffffff0u, W2_RECORDS = 0x80000000u;
+constexpr int W2_UNITS = 56 * 8;                      // FUSE work items per tile: (2x2 pooling window, 8-channel octet)
+
+__device__ __forceinline__ int w2_swz(int row, int col) { return (col & 2) | (((row >> 1) & 1) << 2); }
+
+__device__ __forceinline__ void w2_tr(Frag<bf16>& f, const bf16* lo_ptr, const bf16* hi_ptr) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)lo_ptr);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)hi_ptr);
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+}
+
+struct W2Tile { int n, ty0, tx0; };
+__device__ __forceinline__ W2Tile w2_tile(int tile, int tilesX, int tilesY) {
+    W2Tile t;
+    t.n = tile / (tilesX * tilesY);
+    const int trem = tile - t.n * (tilesX * tilesY);
+    t.ty0 = (trem / tilesX) * W2_TH;
+    t.tx0 = (trem % tilesX) * W2_TW;
+    return t;
+}
+
+// One FUSE work item of a producer thread: registers of the loads in flight plus its validity flags.
+struct W2Unit {
+    union { u32x4 u; bf16x8 v; } y[4], g;
+    bool pv[4], win_ok;
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ slab,
+                                                       int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles,
+                                                       WgradFuse fz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* const xbuf = reinterpret_cast<bf16*>(smem_raw);                 // [2][W2_XBUF]
+    bf16* const dbuf = xbuf + 2 * W2_XBUF;                                // [2][W2_DBUF]
+    float* const cst = reinterpret_cast<float*>(dbuf + 2 * W2_DBUF);      // [5][64]: sc, sh, k, A1, A0
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nCiBlk = Cip / 64;
+    const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * 64;
+    const int S = gridDim.x;
+
+    if (FUSE) {
+        if (tid < 64) {
+            const int ch = co0 + tid;
+            const float sc = fz.ss[ch], sh = fz.ss[Cop + ch];
+            const float mean = fz.mi[ch], inv = fz.mi[Cop + ch];
+            const float k = (ch < fz.Co ? fz.gamma[ch] : 0.f) * inv;
+            const float m1 = fz.training ? fz.sums[ch] * fz.inv_count : 0.f, m2 = fz.training ? fz.sums[Cop + ch] * fz.inv_count : 0.f;
+            cst[tid] = sc; cst[64 + tid] = sh; cst[128 + tid] = k; cst[192 + tid] = -k * m2 * inv; cst[256 + tid] = -k * m1 + k * m2 * inv * mean;
+        }
+    }
+    __syncthreads();                                   // barrier 0: constants visible
+
+    if (wave >= 4) {
+        // ================================================= producers =================================================
+        const int pw = wave - 4, ptid = tid - 256;
+        constexpr int XT = (W2_XW + 3) / 4, DT = (W2_DW + 3) / 4;
+        unsigned xoff[XT];
+        int xyx[XT];
+#pragma unroll
+        for (int k = 0; k < XT; ++k) {
+            int wi = k * 4 + pw;
+            if (wi > W2_XW - 1) wi = W2_XW - 1;                                     // duplicate the last piece
+            const int u = wi * 64 + lane, hp = u >> 3, cp = u & 7;
+            const int hy = hp / W2_HW, hx = hp - hy * W2_HW;
+            xoff[k] = (unsigned)(((hy * W + hx) * Cip + ((cp ^ w2_swz(hy, hx)) << 3)) * 2);
+            xyx[k] = hp < W2_HP ? ((hy << 16) | hx) : (0x7fff << 16);
+        }
+        auto x_dma = [&](const W2Tile& t, bf16* xb) {
+            const long long base = ((long long)(t.n * H + t.ty0 - 1) * W + (t.tx0 - 1)) * Cip + ci0;
+            const __amdgpu_buffer_rsrc_t rs = hyb_rsrc(x + base, W2_RECORDS);
+#pragma unroll
+            for (int k = 0; k < XT; ++k) {
+                const int gy = t.ty0 - 1 + (xyx[k] >> 16), gx = t.tx0 - 1 + (xyx[k] & 0xffff);
+                const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                int wi = k * 4 + pw;
+                if (wi > W2_XW - 1) wi = W2_XW - 1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(xb + wi * 512), 16, valid ? xoff[k] : W2_OOB, 0, 0, 0);
+            }
+        };
+        auto dy_dma = [&](const W2Tile& t, bf16* db) {
+            const long long base = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
+            const __amdgpu_buffer_rsrc_t rs = hyb_rsrc(dy + base, W2_RECORDS);
+#pragma unroll
+            for (int k = 0; k < DT; ++k) {
+                const int wi = k * 4 + pw;                                          // 28 pieces = 4 waves x 7
+                const int u = wi * 64 + lane, px = u >> 3, cp = u & 7;
+                const int ly = px / W2_TW, lx = px - ly * W2_TW;
+                const bool valid = (t.ty0 + ly < H) && (t.tx0 + lx < W);
+                const unsigned off = (unsigned)(((ly * W + lx) * Cop + ((cp ^ w2_swz(ly, lx)) << 3)) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(db + wi * 512), 16, valid ? off : W2_OOB, 0, 0, 0);
+            }
+        };
+        // FUSE work items of this thread: units ptid and ptid + 256 (the second is a repeat of unit 447 for ptid >= 192: same
+        // values to the same addresses).  Branch-free: invalid lanes go out of the descriptors' range.
+        int uoct[2], uwy[2], uwx[2];
+        unsigned yoff[2][4], goff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int u = ptid + i * 256;
+            if (u > W2_UNITS - 1) u = W2_UNITS - 1;
+            uoct[i] = u & 7;
+            const int win = u >> 3;
+            uwy[i] = win / 14; uwx[i] = win - uwy[i] * 14;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yoff[i][j] = (unsigned)((((2 * uwy[i] + (j >> 1)) * W + 2 * uwx[i] + (j & 1)) * Cop + 8 * uoct[i]) * 2);
+            goff[i] = (unsigned)(((uwy[i] * (W >> 1) + uwx[i]) * Cop + 8 * uoct[i]) * 2);
+        }
+        const bool writer = FUSE && fz.dyraw_out && ci0 == 0;
+        auto fuse_load = [&](const W2Tile& t, W2Unit (&un)[2]) {
+            const int Ho = H >> 1, Wo = W >> 1;
+            const long long ybase = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
+            const __amdgpu_buffer_rsrc_t y_rs = hyb_rsrc((const bf16*)fz.y + ybase, W2_RECORDS);
+            const __amdgpu_buffer_rsrc_t g_rs = hyb_rsrc((const bf16*)fz.dp + ((long long)(t.n * Ho + (t.ty0 >> 1)) * Wo + (t.tx0 >> 1)) * Cop + co0, W2_RECORDS);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                un[i].win_ok = ((t.ty0 >> 1) + uwy[i]) < Ho && ((t.tx0 >> 1) + uwx[i]) < Wo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    un[i].pv[j] = (t.ty0 + 2 * uwy[i] + (j >> 1) < H) && (t.tx0 + 2 * uwx[i] + (j & 1) < W);
+                    un[i].y[j].u = __builtin_amdgcn_raw_buffer_load_b128(y_rs, un[i].pv[j] ? yoff[i][j] : W2_OOB, 0, 0);
+                }
+                un[i].g.u = __builtin_amdgcn_raw_buffer_load_b128(g_rs, un[i].win_ok ? goff[i] : W2_OOB, 0, 0);
+            }
+        };
+        auto fuse_compute = [&](const W2Tile& t, W2Unit (&un)[2], bf16* db) {
+            const long long ybase = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
+            const __amdgpu_buffer_rsrc_t o_rs = hyb_rsrc((bf16*)fz.dyraw_out + ybase, writer ? W2_RECORDS : 0u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                union { u32x4 u; bf16x8 v; } o[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = uoct[i] * 8 + e;
+                    const float sc = cst[c], sh = cst[64 + c], kk = cst[128 + c], a1 = cst[192 + c], a0 = cst[256 + c];
+                    float yf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yf[j] = (float)un[i].y[j].v[e];
+                    float vmax = yf[0] * sc + sh;
+                    int am = 0;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        const float v = yf[j] * sc + sh;
+                        if (v > vmax) { vmax = v; am = j; }
+                    }
+                    const float kdy = (vmax > 0.f && un[i].win_ok) ? kk * (float)un[i].g.v[e] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float base = fmaf(yf[j], a1, a0);
+                        o[j].v[e] = (bf16)(un[i].pv[j] ? (am == j ? base + kdy : base) : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ly = 2 * uwy[i] + (j >> 1), lx = 2 * uwx[i] + (j & 1);
+                    *reinterpret_cast<bf16x8*>(db + (ly * W2_TW + lx) * 64 + ((uoct[i] ^ w2_swz(ly, lx)) << 3)) = o[j].v;
+                    __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, un[i].pv[j] ? yoff[i][j] : W2_OOB, 0, 0);
+                }
+            }
+        };
+
+        // tile sequence of this workgroup: blockIdx.x, + S, ...; the tile "after the last" is the last one again (harmless repeat)
+        int tile = blockIdx.x;
+        W2Unit ua[2], ub[2];
+        W2Tile t0 = w2_tile(tile, tilesX, tilesY);
+        x_dma(t0, xbuf);
+        if (FUSE) { fuse_load(t0, ua); fuse_compute(t0, ua, dbuf); } else dy_dma(t0, dbuf);
+        W2Tile t1 = w2_tile(tile + S < numTiles ? tile + S : tile, tilesX, tilesY);
+        if (FUSE) fuse_load(t1, ua);                   // in flight across the barrier
+        __syncthreads();                               // barrier 1: tile 0 staged
+        int it = 0;
+        for (; tile < numTiles; tile += 2 * S, it += 2) {
+            // even iteration: consumers read buffers 0; fill buffers 1 with t1 (registers ua), prefetch t2 into ub
+            {
+                const int t2i = tile + 2 * S < numTiles ? tile + 2 * S : (tile + S < numTiles ? tile + S : tile);
+                const W2Tile t2 = w2_tile(t2i, tilesX, tilesY);
+                x_dma(t1, xbuf + W2_XBUF);
+                if (FUSE) { fuse_load(t2, ub); fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
+                __syncthreads();
+                t1 = t2;
+            }
+            if (tile + S >= numTiles) break;
+            // odd iteration: consumers read buffers 1; fill buffers 0 with t1 (registers ub), prefetch the next into ua
+            {
+                const int t2i = tile + 3 * S < numTiles ? tile + 3 * S : (tile + 2 * S < numTiles ? tile + 2 * S : tile + S);
+                const W2Tile t2 = w2_tile(t2i, tilesX, tilesY);
+                x_dma(t1, xbuf);
+                if (FUSE) { fuse_load(t2, ua); fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
+                __syncthreads();
+                t1 = t2;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =================================================== consumers ===================================================
+    const int cit = wave;
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    // fragment addresses (elements).  dy tile pixel (row, col) -> (row*28 + col)*64; x halo pixel -> (row*30 + col)*64.
+    int aoff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int chunk = c * 2 + (pp >> 1);
+        aoff[c] = (2 * g * W2_TW + qq) * 64 + (((chunk ^ ((qq & 2) | ((g & 1) << 2))) << 3) | ((pp & 1) << 2));
+    }
+    int boff[3][2];      // [kw][row parity class]: swizzled chunk offset inside the pixel
+    {
+        const int chunk = cit * 2 + (pp >> 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int sy = 0; sy < 2; ++sy)
+                boff[kw][sy] = ((chunk ^ (((kw + qq) & 2) | ((((g & 1) ^ sy)) << 2))) << 3) | ((pp & 1) << 2);
+    }
+    const int bpix = (2 * g * W2_HW + qq) * 64;
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                   // barrier 1: tile 0 staged
+    int it = 0;
+    for (int tile = blockIdx.x; tile < numTiles; tile += S, ++it) {
+        const bf16* xb = xbuf + (it & 1) * W2_XBUF;
+        const bf16* db = dbuf + (it & 1) * W2_DBUF;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {                  // k-step j: tile columns 4j .. 4j+3, rows 2g, 2g+1
+            Frag<bf16> a[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w2_tr(a[c], db + aoff[c] + j * 256, db + aoff[c] + j * 256 + W2_TW * 64);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                // rows 2g+kh (lo) and 2g+kh+1 (hi): swizzle class = ((row >> 1) & 1) ^ (g & 1)
+                const bf16* lo = xb + bpix + (kh * W2_HW + 4 * j + kw) * 64 + boff[kw][(kh >> 1) & 1];
+                const bf16* hi = xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * 64 + boff[kw][((kh + 1) >> 1) & 1];
+                Frag<bf16> b;
+                w2_tr(b, lo, hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[tap][c] = mma32(a[c], b, acc[tap][c]);
+            }
+        }
+        __syncthreads();                               // the other pair of images is complete, this pair may be overwritten
+    }
+
+    // D[row = co][col = ci]: lane holds ci = lane&15, co rows 4g + r
+    float* out = slab + (long long)blockIdx.x * Cop * 9 * Cip;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + 4 * g + r;
+                out[((long long)co * 9 + tap) * Cip + ci0 + cit * 16 + (lane & 15)] = acc[tap][c][r];
+            }
+}
+
 struct WgradPlan { int S, gy, cit; long long per_slab; };
 
 inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
@@ -294,6 +579,32 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
     const WgradPlan p = wgrad_plan(first, N, H, W, Cip, Cop);
     if (ws_bytes < (size_t)p.S * p.per_slab * sizeof(float)) return HYB_E_WORKSPACE;
     float* slab = (float*)ws;
+    if constexpr (sizeof(T) == 2) {
+        static const int v2 = getenv("HYB_WGRAD_V2") ? atoi(getenv("HYB_WGRAD_V2")) : 1;
+        const int blocks = (Cop / 64) * (Cip / 64);
+        if (v2 && !first && Cip % 64 == 0 && Cop % 64 == 0 && blocks <= 256 && (long long)12 * W * (Cip > Cop ? Cip : Cop) < (1ll << 29)) {
+            const int tX = hyb_cdiv(W, W2_TW), tY = hyb_cdiv(H, W2_TH);
+            const long long nT = (long long)N * tX * tY;
+            int S = 256 / blocks;
+            if (S > p.S) S = p.S;                          // never more slabs than the workspace query promised
+            if (S > nT) S = (int)nT;
+            const void* f = fz ? (const void*)wgrad_v2_kernel<true> : (const void*)wgrad_v2_kernel<false>;
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS);
+            if (e != hipSuccess) return (int)e;
+            HybProfileHook* hook2 = hyb_find_hook(2, Cip, Cop);
+            if (hook2) hipEventRecord(hook2->ev0, st);
+            if (fz) hipLaunchKernelGGL(wgrad_v2_kernel<true>, dim3(S, blocks), dim3(512), W2_LDS, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip,
+                                       Cop, tX, tY, (int)nT, *fz);
+            else hipLaunchKernelGGL(wgrad_v2_kernel<false>, dim3(S, blocks), dim3(512), W2_LDS, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip,
+                                    Cop, tX, tY, (int)nT, WgradFuse{});
+            if (hook2) hipEventRecord(hook2->ev1, st);
+            HYB_LAUNCH_CHECK();
+            if (!dw) return 0;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(1024), 0, st, slab, dw, S, first, Co, Ci, Cop, Cip, p.per_slab);
+            HYB_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int tilesX = hyb_cdiv(W, WG_TW), tilesY = hyb_cdiv(H, WG_TH);
     const int numTiles = N * tilesX * tilesY;
     dim3 grid(p.S, p.gy);

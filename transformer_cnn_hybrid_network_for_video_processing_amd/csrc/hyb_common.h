@@ -108,6 +108,16 @@ template <> struct Vec8<float> {
 };
 
 // ---------------------------------------------------------------------------------------
+// Buffer descriptor over [p, p + records) bytes, built from wave-uniform inputs.  The readfirstlane makes the uniformity
+// provable to the compiler (otherwise every buffer op is wrapped in a waterfall loop).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hyb_rsrc(const void* p, unsigned records) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(records), 0x00020000);
+}
+
+// ---------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
