@@ -5,6 +5,11 @@
 //   MODE 1  conv -> scale/shift -> ReLU -> 2x2 max (lane shuffles) -> pooled NHWC output          reads x, writes pooled
 //   MODE 2  conv -> argmax/ReLU routing of dpooled -> sum(dy), sum(dy*xhat)                        reads x, dpooled
 //   MODE 3  conv -> dense BN-backward gradient tile in LDS -> weight gradient (contraction over pixels)  reads x, dpooled
+//   MODE 4  the whole backward in ONE pass (replaces 2 + 3 in training and eval): BatchNorm backward is linear in the routed
+//           gradient dz (= dpooled at the window's arg-max if the ReLU let it through, else 0), so with the im2col matrix P
+//             S1 = sum_pix dz (x) P,   G = sum_pix P (x) P  (P carries a ones column: G[:,36] = sum P, S1[:,36] = sum dz)
+//           everything else follows from tiny matrices in a finalize kernel:  sum dz*y = rowdot(W, S1),
+//             dW = gamma*inv * [ S1 - m1*SP - m2*inv*(W G - mean*SP) ],  m1 = sum dz / n,  m2 = sum dz*xhat / n.
 // A workgroup walks 8x32-pixel tiles.  The fp32 halo (10x34 pixels, prefetched one tile ahead into registers) is converted
 // to T and expanded into an im2col matrix P[pixel][k = tap*4 + c] in LDS; P rows feed the conv MFMA (k contiguous) and
 // P columns feed the wgrad MFMA through transposed LDS reads, so no scalar gathers are needed.
@@ -16,6 +21,7 @@ constexpr int S1_TH = 8, S1_TW = 32, S1_HW = S1_TW + 2, S1_HH = S1_TH + 2, S1_HP
 constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
 constexpr int S1_KP = 64, S1_PS = S1_KP + 8;   // padded K and P row stride (elements)
 constexpr int S1_MAXPART = 1024;
+constexpr int S1_BWD_PART = 512;               // workgroups (= partial rows) of the one-pass backward
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;
 
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     T* P = img + S1_IMG * 4;                                       // MODE 3: im2col [256][S1_PS]
     constexpr int DS = NT * 16 + 8;
     T* dyt = P + S1_NPIX * S1_PS;                                  // MODE 3: [256][DS]
-    float* wgstat = reinterpret_cast<float*>(MODE == 3 ? (dyt + S1_NPIX * DS) : P);   // [2][NT*16] (modes 0, 2)
+    float* wgstat = reinterpret_cast<float*>(MODE >= 3 ? (dyt + S1_NPIX * DS) : P);   // [2][NT*16] (modes 0, 2)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     const int Ho = H >> 1, Wo = W >> 1;
     const T* wp = (const T*)a.wp;
 
-    if (MODE == 3) {   // zero the im2col padding columns (k >= 36) once; they are never written again
+    if (MODE >= 3) {   // zero the im2col padding columns (k >= 36) once; they are never written again (MODE 4: k = 36 is the ones column)
         for (int i = tid; i < S1_NPIX * (S1_PS - 36); i += 256) {
             const int pix = i / (S1_PS - 36), k = 36 + i % (S1_PS - 36);
             P[pix * S1_PS + k] = from_f32<T>(0.f);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             for (int r = 0; r < 4; ++r) {
                 const int ch = co_base + q * (NT * 4) + t * 4 + r;
                 c_sc[t][r] = a.ss[ch]; c_sh[t][r] = a.ss[Cop + ch];
-                if (MODE >= 2) { c_mean[t][r] = a.mi[ch]; c_inv[t][r] = a.mi[Cop + ch]; }
+                if (MODE == 2 || MODE == 3) { c_mean[t][r] = a.mi[ch]; c_inv[t][r] = a.mi[Cop + ch]; }
                 if (MODE == 3) {
                     // dyraw = k*(dy - m1 - xhat*m2), xhat = (y - mean)*inv  ==  A1*y + A0 + k*dy
                     const float k = (ch < a.Co ? a.gamma[ch] : 0.f) * a.mi[Cop + ch];
@@ -159,8 +165,13 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc1[t][r] = 0.f; acc2[t][r] = 0.f; }
     }
-    f32x4 wacc[3][NT];                        // MODE 3: dW[co tile][k tile] partials of this wave
-    if (MODE == 3) {
+    f32x4 wacc[3][NT];                        // MODE 3/4: dW (S1) [co tile][k tile] partials of this wave
+    f32x4 gacc[6];                            // MODE 4: upper triangle of the Gram matrix G[k tile][k tile]
+    if (MODE == 4) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE >= 3) {
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
@@ -234,6 +245,21 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             for (int tap = 0; tap < 9; ++tap)
                 *reinterpret_cast<Quad<T>*>(P + tid * S1_PS + tap * 4) =
                     *reinterpret_cast<const Quad<T>*>(img + ((ty + tap / 3) * S1_IW + tx + 3 + tap % 3) * 4);
+        }
+        if (MODE == 4) {   // same, but rows of pixels outside the image are zero (they must not enter G) and column 36 flags validity
+            const int ty = tid >> 5, tx = tid & 31;
+            const bool pvalid = (ty0 + ty < H) && (tx0 + tx < W);
+            Quad<T> zq;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zq.v[c] = from_f32<T>(0.f);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const Quad<T> v = *reinterpret_cast<const Quad<T>*>(img + ((ty + tap / 3) * S1_IW + tx + 3 + tap % 3) * 4);
+                *reinterpret_cast<Quad<T>*>(P + tid * S1_PS + tap * 4) = pvalid ? v : zq;
+            }
+            Quad<T> one = zq;
+            one.v[0] = from_f32<T>(pvalid ? 1.f : 0.f);
+            *reinterpret_cast<Quad<T>*>(P + tid * S1_PS + 36) = one;
         }
 
         // ---- conv of this wave's 8x8 block: 4 window positions x NT channel tiles
@@ -319,8 +345,12 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                             o[j].set(e, pixvalid[j] ? (am == j ? base + kdy : base) : 0.f);
                         }
                     }
+                    if (MODE == 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j].set(e, am == j ? dy : 0.f);      // routed gradient dz (win_ok implies the pixel is valid)
+                    }
                 }
-                if (MODE == 3) {
+                if (MODE >= 3) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int pix = (2 * wy + (j >> 1)) * S1_TW + wave * 8 + 2 * wx + (j & 1);
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                 }
             }
         }
-        if (MODE == 3) {
+        if (MODE >= 3) {
             __syncthreads();
             // dW[co][k] += sum over this wave's 2 tile rows (32 pixels = one k32 step each)
 #pragma unroll
@@ -338,12 +368,16 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                 Frag<T> af[NT];
 #pragma unroll
                 for (int c = 0; c < NT; ++c) tr_frag_s1(af[c], dyt + (row * S1_TW + 4 * q) * DS + c * 16, DS, 16, lane);
+                Frag<T> bf[3];
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
-                    Frag<T> bf;
-                    tr_frag_s1(bf, P + (row * S1_TW + 4 * q) * S1_PS + kt * 16, S1_PS, 16, lane);
+                    tr_frag_s1(bf[kt], P + (row * S1_TW + 4 * q) * S1_PS + kt * 16, S1_PS, 16, lane);
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf, wacc[kt][c]);
+                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf[kt], wacc[kt][c]);
+                }
+                if (MODE == 4 && blockIdx.y == 0) {       // Gram matrix of the patches: A and B fragments have the same lane layout
+                    gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
+                    gacc[3] = mma32(bf[1], bf[1], gacc[3]); gacc[4] = mma32(bf[1], bf[2], gacc[4]); gacc[5] = mma32(bf[2], bf[2], gacc[5]);
                 }
             }
         }
@@ -366,6 +400,35 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             const float v = (wgstat[(0 * 2 + which) * (NT * 16) + cl] + wgstat[(1 * 2 + which) * (NT * 16) + cl]) +
                             (wgstat[(2 * 2 + which) * (NT * 16) + cl] + wgstat[(3 * 2 + which) * (NT * 16) + cl]);
             a.part[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = v;
+        }
+    }
+    if (MODE == 4) {
+        // combine the 4 waves through LDS (reusing P/dyt): row = [S1: Cop x 48][G: 48 x 48 (upper triangle tiles filled)]
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(P);                  // [4][NT*16*48 + 2304]
+        constexpr int RW = NT * 16 * 48 + 2304;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * RW + (c * 16 + 4 * q + r) * 48 + kt * 16 + p] = wacc[kt][c][r];
+        auto put_g = [&](int i, int gi, int gj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * RW + NT * 16 * 48 + (gi * 16 + 4 * q + r) * 48 + gj * 16 + p] = gacc[i][r];
+        };
+        put_g(0, 0, 0); put_g(1, 0, 1); put_g(2, 0, 2); put_g(3, 1, 1); put_g(4, 1, 2); put_g(5, 2, 2);
+        __syncthreads();
+        const long long roww = (long long)Cop * 48 + 2304;
+        float* out = a.part + (long long)blockIdx.x * roww;
+        for (int i = tid; i < NT * 16 * 48; i += 256)
+            out[(long long)co_base * 48 + i] = (red[i] + red[RW + i]) + (red[2 * RW + i] + red[3 * RW + i]);
+        if (blockIdx.y == 0) {
+            for (int i = tid; i < 2304; i += 256) {
+                const int gr = i / 48, gc = i % 48;
+                const int o = NT * 16 * 48 + i;
+                out[(long long)Cop * 48 + i] = (gr / 16 <= gc / 16) ? (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]) : 0.f;
+            }
         }
     }
     if (MODE == 3) {
@@ -397,6 +460,44 @@ __global__ __launch_bounds__(1024) void s1_wgrad_reduce_kernel(const float* __re
     if (co < Co && tap < 9 && ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = v;
 }
 
+// MODE 4 finalize.  red = [S1: Cop x 48][G: 48 x 48, only tiles (i <= j) valid]; one thread per (co, k).
+template <typename T>
+__global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const float* __restrict__ red, const T* __restrict__ wp, const float* __restrict__ mi,
+                                                              const float* __restrict__ gamma, int training, float inv_count, int Co, int Ci,
+                                                              int Cop, float* __restrict__ dw, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * 36) return;
+    const int co = i / 36, k = i - co * 36;
+    const float* S1 = red + (long long)co * 48;
+    const float* G = red + (long long)Cop * 48;
+    auto g_at = [&](int r, int c) { return (r / 16 <= c / 16) ? G[r * 48 + c] : G[c * 48 + r]; };      // symmetric
+    const float mean = mi[co], inv = mi[Cop + co];
+    const float sdz = S1[36];
+    float sdzy = 0.f, wg = 0.f;
+    for (int kk = 0; kk < 36; ++kk) {
+        const float w = to_f32<T>(wp[(long long)co * 64 + kk]);
+        sdzy = fmaf(w, S1[kk], sdzy);
+        wg = fmaf(w, g_at(kk, k), wg);
+    }
+    const float sdzx = (sdzy - mean * sdz) * inv;              // sum dz * xhat
+    const float m1 = training ? sdz * inv_count : 0.f, m2 = training ? sdzx * inv_count : 0.f;
+    const float sp = g_at(k, 36);
+    const float v = gamma[co] * inv * (S1[k] - m1 * sp - m2 * inv * (wg - mean * sp));
+    const int tap = k >> 2, ci = k & 3;
+    if (ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = v;
+    if (k == 0) {
+        if (dbeta) dbeta[co] = sdz;
+        if (dgamma) dgamma[co] = sdzx;
+    }
+}
+
+// fixed-order sum of the MODE 4 partial rows
+__global__ __launch_bounds__(1024) void s1_rows_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int G, long long n) {
+    long long i; float v;
+    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
+}
+
 // packed first-layer weights for this path: T [Cop][64], k = tap*4 + c
 template <typename T>
 __global__ void s1_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, long long total) {
@@ -422,8 +523,13 @@ __global__ __launch_bounds__(1024) void s1_rows_reduce_kernel(const float* __res
 template <typename T, int NT, int MODE>
 size_t s1_lds_bytes() {
     size_t el = (size_t)S1_IMG * 4;
-    if (MODE == 3) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
-    return el * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
+    if (MODE >= 3) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
+    size_t bytes = el * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
+    if (MODE == 4) {                                       // the end-of-kernel combine reuses P/dyt as [4][NT*16*48 + 2304] floats
+        const size_t need = (size_t)S1_IMG * 4 * sizeof(T) + (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
+        if (need > bytes) bytes = need;
+    }
+    return bytes;
 }
 
 template <typename T, int NT, int MODE>
@@ -456,7 +562,7 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
 }
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * Cop * 48 * 4);
+    return al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 4) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
 }
 
 static int s1_grid(long long numTiles) {
@@ -506,7 +612,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
-    float* sums = (float*)ws;                    ws += al256(2 * (size_t)Cop * 4);
+    float* sums = (float*)ws;                    ws += al256(((size_t)Cop * 48 + 2304) * 4);      // reduced row [S1][G]
     float* part = (float*)ws;
     if (packed_in) {
         wp = (T*)packed_in;                      // packed by the forward pass
@@ -524,14 +630,16 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
-    const int gx = s1_grid(numTiles);
-    int rc = s1_dispatch<T, 2>(a, gx, st);
+    // one pass over x and dpooled (MODE 4), a fixed-order sum of the partial rows, and a finalize on tiny matrices
+    int gx = (int)(numTiles < S1_BWD_PART ? numTiles : S1_BWD_PART);
+    if (gx < 1) gx = 1;
+    const long long roww = (long long)Cop * 48 + 2304;
+    int rc = s1_dispatch<T, 4>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_rows_reduce_kernel, dim3(hyb_cdiv(2 * Cop, 32)), dim3(1024), 0, st, part, sums, gx, 2 * Cop, dgamma, dbeta, Co, Cop);
+    hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(roww, 32)), dim3(1024), 0, st, part, sums, gx, roww);
     HYB_LAUNCH_CHECK();
-    rc = s1_dispatch<T, 3>(a, gx, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(s1_wgrad_reduce_kernel, dim3(hyb_cdiv((long long)Cop * 48, 32)), dim3(1024), 0, st, part, dweight, gx, Co, Ci, Cop);
+    hipLaunchKernelGGL(s1_bwd_finalize_kernel<T>, dim3(hyb_cdiv(Co * 36, 256)), dim3(256), 0, st, sums, wp, mean_invstd, gamma, training,
+                       a.inv_count, Co, Ci, Cop, dweight, dgamma, dbeta);
     HYB_LAUNCH_CHECK();
     return 0;
 }
