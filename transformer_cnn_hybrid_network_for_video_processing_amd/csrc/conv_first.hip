@@ -1,11 +1,9 @@
 // Stage 1 (Conv3x3 -> BatchNorm -> ReLU -> MaxPool on the NCHW fp32 clip frames, UNet.py:58-60 + UNet.py:13) WITHOUT ever
 // writing the full-resolution conv output: with Ci <= 4 the conv is K = 9*4 = 36 deep, far cheaper to recompute on the
-// matrix cores than to store and re-read (411 MB of bf16 per step at config 2).  One kernel template, four modes:
+// matrix cores than to store and re-read (411 MB of bf16 per step at config 2).  One kernel template, three modes:
 //   MODE 0  conv -> per-channel sum / sum of squares (BN batch statistics)                      reads x
 //   MODE 1  conv -> scale/shift -> ReLU -> 2x2 max (lane shuffles) -> pooled NHWC output          reads x, writes pooled
-//   MODE 2  conv -> argmax/ReLU routing of dpooled -> sum(dy), sum(dy*xhat)                        reads x, dpooled
-//   MODE 3  conv -> dense BN-backward gradient tile in LDS -> weight gradient (contraction over pixels)  reads x, dpooled
-//   MODE 4  the whole backward in ONE pass (replaces 2 + 3 in training and eval): BatchNorm backward is linear in the routed
+//   MODE 4  the whole backward in ONE pass over x and dpooled (training and eval): BatchNorm backward is linear in the routed
 //           gradient dz (= dpooled at the window's arg-max if the ReLU let it through, else 0), so with the im2col matrix P
 //             S1 = sum_pix dz (x) P,   G = sum_pix P (x) P  (P carries a ones column: G[:,36] = sum P, S1[:,36] = sum dz)
 //           everything else follows from tiny matrices in a finalize kernel:  sum dz*y = rowdot(W, S1),
@@ -113,7 +111,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     T* P = img + S1_IMG * 4;                                       // MODE 3: im2col [256][S1_PS]
     constexpr int DS = NT * 16 + 8;
     T* dyt = P + S1_NPIX * S1_PS;                                  // MODE 3: [256][DS]
-    float* wgstat = reinterpret_cast<float*>(MODE >= 3 ? (dyt + S1_NPIX * DS) : P);   // [2][NT*16] (modes 0, 2)
+    float* wgstat = reinterpret_cast<float*>(MODE == 4 ? (dyt + S1_NPIX * DS) : P);   // [2][NT*16] (mode 0)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,13 +121,13 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
     const int Ho = H >> 1, Wo = W >> 1;
     const T* wp = (const T*)a.wp;
 
-    if (MODE >= 3) {   // zero the im2col padding columns (k >= 36) once; they are never written again (MODE 4: k = 36 is the ones column)
+    if (MODE == 4) {   // zero the im2col padding columns (k >= 36) once; they are never written again (k = 36 is the ones column)
         for (int i = tid; i < S1_NPIX * (S1_PS - 36); i += 256) {
             const int pix = i / (S1_PS - 36), k = 36 + i % (S1_PS - 36);
             P[pix * S1_PS + k] = from_f32<T>(0.f);
         }
     }
-    // (modes 0, 2) per-wave slots [4][2][NT*16]: no atomics, fixed-order combine at the end (bit-reproducible)
+    // (mode 0) per-wave slots [4][2][NT*16]: no atomics, fixed-order combine at the end (bit-reproducible)
 
     Frag<T> w0[NT], w1[NT];
 #pragma unroll
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
         frag_load(w0[t], row);
         frag_load(w1[t], row + 32);
     }
-    float c_sc[NT][4], c_sh[NT][4], c_mean[NT][4], c_inv[NT][4], c_k[NT][4], c_m1[NT][4], c_m2[NT][4];
+    float c_sc[NT][4], c_sh[NT][4];
     if (MODE >= 1) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -146,32 +144,22 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             for (int r = 0; r < 4; ++r) {
                 const int ch = co_base + q * (NT * 4) + t * 4 + r;
                 c_sc[t][r] = a.ss[ch]; c_sh[t][r] = a.ss[Cop + ch];
-                if (MODE == 2 || MODE == 3) { c_mean[t][r] = a.mi[ch]; c_inv[t][r] = a.mi[Cop + ch]; }
-                if (MODE == 3) {
-                    // dyraw = k*(dy - m1 - xhat*m2), xhat = (y - mean)*inv  ==  A1*y + A0 + k*dy
-                    const float k = (ch < a.Co ? a.gamma[ch] : 0.f) * a.mi[Cop + ch];
-                    const float m1 = a.training ? a.sums[ch] * a.inv_count : 0.f;
-                    const float m2 = a.training ? a.sums[Cop + ch] * a.inv_count : 0.f;
-                    c_k[t][r] = k;
-                    c_m2[t][r] = -k * m2 * a.mi[Cop + ch];                       // A1
-                    c_m1[t][r] = -k * m1 + k * m2 * a.mi[Cop + ch] * a.mi[ch];   // A0
-                }
             }
     }
-    float acc1[NT][4], acc2[NT][4];           // MODE 0: sum / sum sq ; MODE 2: sum(dy) / sum(dy*xhat)   (per lane, all tiles)
-    if (MODE == 0 || MODE == 2) {
+    float acc1[NT][4], acc2[NT][4];           // MODE 0: sum / sum of squares (per lane, all tiles)
+    if (MODE == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc1[t][r] = 0.f; acc2[t][r] = 0.f; }
     }
-    f32x4 wacc[3][NT];                        // MODE 3/4: dW (S1) [co tile][k tile] partials of this wave
+    f32x4 wacc[3][NT];                        // MODE 4: S1 [co tile][k tile] partials of this wave
     f32x4 gacc[6];                            // MODE 4: upper triangle of the Gram matrix G[k tile][k tile]
     if (MODE == 4) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (MODE >= 3) {
+    if (MODE == 4) {
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
@@ -202,7 +190,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             pf[c] = v;
         }
     };
-    // MODE >= 2: this lane's dpooled values (window (wy, wx) of the wave's 8x8 block) are prefetched one tile ahead too
+    // MODE == 4: this lane's dpooled values (window (wy, wx) of the wave's 8x8 block) are prefetched one tile ahead too
     Vec8<T> gpf[NT / 2];
     auto prefetch_dp = [&](int tile) {
         int n, ty0, tx0;
@@ -214,7 +202,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             if (oy < Ho && ox < Wo) gpf[h8].load(dsrc + h8 * 8); else gpf[h8].zero();
         }
     };
-    if ((int)blockIdx.x < a.numTiles) { prefetch(blockIdx.x); if (MODE >= 2) prefetch_dp(blockIdx.x); }
+    if ((int)blockIdx.x < a.numTiles) { prefetch(blockIdx.x); if (MODE == 4) prefetch_dp(blockIdx.x); }
 
     for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
         int n, ty0, tx0;
@@ -231,22 +219,16 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
         }
         __syncthreads();
         Vec8<T> gcur[NT / 2];
-        if (MODE >= 2) {
+        if (MODE == 4) {
 #pragma unroll
             for (int h8 = 0; h8 < NT / 2; ++h8) gcur[h8] = gpf[h8];
         }
         if (tile + (int)gridDim.x < a.numTiles) {                                // in flight under this tile's work
             prefetch(tile + gridDim.x);
-            if (MODE >= 2) prefetch_dp(tile + gridDim.x);
+            if (MODE == 4) prefetch_dp(tile + gridDim.x);
         }
-        if (MODE == 3) {   // im2col for the wgrad B operand: pixel tid, 9 taps x 4 channels
-            const int ty = tid >> 5, tx = tid & 31;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                *reinterpret_cast<Quad<T>*>(P + tid * S1_PS + tap * 4) =
-                    *reinterpret_cast<const Quad<T>*>(img + ((ty + tap / 3) * S1_IW + tx + 3 + tap % 3) * 4);
-        }
-        if (MODE == 4) {   // same, but rows of pixels outside the image are zero (they must not enter G) and column 36 flags validity
+        if (MODE == 4) {   // im2col (pixel tid, 9 taps x 4 channels) for the pixel contractions; rows of pixels outside the image are zero
+                           // (they must not enter G) and column 36 flags validity
             const int ty = tid >> 5, tx = tid & 31;
             const bool pvalid = (ty0 + ty < H) && (tx0 + tx < W);
             Quad<T> zq;
@@ -311,10 +293,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                 }
             }
         }
-        if (MODE >= 2) {
-            bool pixvalid[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pixvalid[j] = (gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W;
+        if (MODE == 4) {
 #pragma unroll
             for (int h8 = 0; h8 < NT / 2; ++h8) {
                 const Vec8<T> g = gcur[h8];
@@ -332,36 +311,17 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                         if (v > vmax) { vmax = v; am = j; }
                     }
                     const float dy = (vmax > 0.f && win_ok) ? g.get(e) : 0.f;
-                    if (MODE == 2) {
-                        const float ysel = am == 0 ? acc[0][t][r] : am == 1 ? acc[1][t][r] : am == 2 ? acc[2][t][r] : acc[3][t][r];
-                        acc1[t][r] += dy;
-                        acc2[t][r] += dy * (ysel - c_mean[t][r]) * c_inv[t][r];
-                    }
-                    if (MODE == 3) {
-                        const float kdy = c_k[t][r] * dy;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float base = fmaf(acc[j][t][r], c_m2[t][r], c_m1[t][r]);
-                            o[j].set(e, pixvalid[j] ? (am == j ? base + kdy : base) : 0.f);
-                        }
-                    }
-                    if (MODE == 4) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j].set(e, am == j ? dy : 0.f);      // routed gradient dz (win_ok implies the pixel is valid)
-                    }
+                    for (int j = 0; j < 4; ++j) o[j].set(e, am == j ? dy : 0.f);          // routed gradient dz (win_ok implies the pixel is valid)
                 }
-                if (MODE >= 3) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int pix = (2 * wy + (j >> 1)) * S1_TW + wave * 8 + 2 * wx + (j & 1);
-                        o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int pix = (2 * wy + (j >> 1)) * S1_TW + wave * 8 + 2 * wx + (j & 1);
+                    o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
                 }
             }
-        }
-        if (MODE >= 3) {
             __syncthreads();
-            // dW[co][k] += sum over this wave's 2 tile rows (32 pixels = one k32 step each)
+            // S1[co][k] (and G) += sum over this wave's 2 tile rows (32 pixels = one k32 step each)
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = wave * 2 + rr;
@@ -383,7 +343,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
         }
     }
 
-    if (MODE == 0 || MODE == 2) {
+    if (MODE == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -431,33 +391,6 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             }
         }
     }
-    if (MODE == 3) {
-        // combine the 4 waves through LDS (reusing P/dyt), then one slab row per workgroup: slab[co][k], k = tap*4 + c (48 kept)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(P);                  // [4][NT*16][48]
-#pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-            for (int c = 0; c < NT; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[(wave * (NT * 16) + c * 16 + 4 * q + r) * 48 + kt * 16 + p] = wacc[kt][c][r];
-        __syncthreads();
-        float* out = a.part + (long long)blockIdx.x * Cop * 48;
-        for (int i = tid; i < NT * 16 * 48; i += 256) {
-            const float v = (red[i] + red[NT * 16 * 48 + i]) + (red[2 * NT * 16 * 48 + i] + red[3 * NT * 16 * 48 + i]);
-            out[(long long)(co_base + i / 48) * 48 + i % 48] = v;
-        }
-    }
-}
-
-// dw[co][ci][tap] = sum_s slab[s][co][tap*4 + ci]; fixed order
-__global__ __launch_bounds__(1024) void s1_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
-                                                               int Cop) {
-    long long i; float v;
-    if (!rows_reduce_1024(slab, S, (long long)Cop * 48, i, v)) return;
-    const int kk = (int)(i % 48), co = (int)(i / 48);
-    const int tap = kk >> 2, ci = kk & 3;
-    if (co < Co && tap < 9 && ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = v;
 }
 
 // MODE 4 finalize.  red = [S1: Cop x 48][G: 48 x 48, only tiles (i <= j) valid]; one thread per (co, k).
@@ -510,20 +443,10 @@ __global__ void s1_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, 
     wp[i] = from_f32<T>(v);
 }
 
-// partial rows -> sums[2][Cop] (fixed order), plus dbeta / dgamma for c < Co
-__global__ __launch_bounds__(1024) void s1_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int Co, int Cop) {
-    long long i; float v;
-    if (!rows_reduce_1024(part, G, n, i, v)) return;
-    out[i] = v;
-    if (i < Cop) { if (dbeta && i < Co) dbeta[i] = v; }
-    else if (dgamma && i - Cop < Co) dgamma[i - Cop] = v;
-}
-
 template <typename T, int NT, int MODE>
 size_t s1_lds_bytes() {
     size_t el = (size_t)S1_IMG * 4;
-    if (MODE >= 3) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
+    if (MODE == 4) el += (size_t)S1_NPIX * S1_PS + (size_t)S1_NPIX * (NT * 16 + 8);
     size_t bytes = el * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
     if (MODE == 4) {                                       // the end-of-kernel combine reuses P/dyt as [4][NT*16*48 + 2304] floats
         const size_t need = (size_t)S1_IMG * 4 * sizeof(T) + (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
