@@ -18,7 +18,7 @@ namespace {
 constexpr int S1_TH = 8, S1_TW = 32, S1_HW = S1_TW + 2, S1_HH = S1_TH + 2, S1_HP = S1_HH * S1_HW;   // halo 10 x 34 = 340 pixels
 constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
 constexpr int S1_KP = 64, S1_PS = S1_KP + 8;   // padded K and P row stride (elements)
-constexpr int S1_MAXPART = 1024;
+constexpr int S1_MAXPART = 512;                // workgroups (= partial statistics rows) of the forward passes: two per CU
 constexpr int S1_BWD_PART = 512;               // workgroups (= partial rows) of the one-pass backward
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;

@@ -559,6 +559,26 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             }
 }
 
+// few slabs (second-generation kernel: S = 256 / blocks): one thread per output element walks the S slabs; loads are issued
+// eight at a time, the additions keep the slab order
+__global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
+                                                               int Cip, long long per_slab) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_slab) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = slab[(long long)(k + j) * per_slab + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < S; ++k) s += slab[(long long)k * per_slab + i];
+    const int ci = (int)(i % Cip), tap = (int)((i / Cip) % 9), co = (int)(i / ((long long)9 * Cip));
+    if (ci < Ci && co < Co) dw[((long long)co * Ci + ci) * 9 + tap] = s;
+}
+
 struct WgradPlan { int S, gy, cit; long long per_slab; };
 
 inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
@@ -600,7 +620,8 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
             if (hook2) hipEventRecord(hook2->ev1, st);
             HYB_LAUNCH_CHECK();
             if (!dw) return 0;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(1024), 0, st, slab, dw, S, first, Co, Ci, Cop, Cip, p.per_slab);
+            if (S <= 64) hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3(hyb_cdiv(p.per_slab, 256)), dim3(256), 0, st, slab, dw, S, Co, Ci, Cip, p.per_slab);
+            else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(1024), 0, st, slab, dw, S, first, Co, Ci, Cop, Cip, p.per_slab);
             HYB_LAUNCH_CHECK();
             return 0;
         }

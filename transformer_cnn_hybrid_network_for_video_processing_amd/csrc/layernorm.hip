@@ -139,17 +139,31 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
     }
 }
 
+// mean over the S tokens of feature d of clip b: the loads are issued eight at a time (independent), the additions keep the
+// order of a plain loop
+template <typename T>
+__device__ __forceinline__ float token_mean(const T* __restrict__ x, int b, int S, int D, int d) {
+    const T* col = x + (long long)b * S * D + d;
+    float s = 0.f;
+    int t = 0;
+    for (; t + 8 <= S; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f32<T>(col[(long long)(t + j) * D]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; t < S; ++t) s += to_f32<T>(col[(long long)t * D]);
+    return s / (float)S;
+}
+
 // ---- head: logits[b][c] = bias[c] + sum_d mean_s(x[b][s][d]) * W[c][d] ------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ logits, int S, int D, int C) {
     extern __shared__ float pooled[];          // [D]
     const int b = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float s = 0.f;
-        for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
-        pooled[d] = s / (float)S;
-    }
+    for (int d = threadIdx.x; d < D; d += blockDim.x) pooled[d] = token_mean(x, b, S, D, d);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = wave; c < C; c += 4) {
@@ -171,27 +185,33 @@ __global__ void head_bwd_dx_kernel(const float* __restrict__ W, const float* __r
     }
 }
 // dW[c][d] = sum_b dlogits[b][c] * mean_s x[b][s][d];  db[c] = sum_b dlogits[b][c]
-// grid (D/64, C-chunks of 16): each thread owns one feature d, pools it once per clip, updates 16 class rows
+// grid (D/64, C-chunks of 16), 256 threads = 64 features x 4 clip groups (clips b = group, group + 4, ...); the groups are
+// combined through LDS in a fixed order
 template <typename T>
-__global__ void head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ dW, float* __restrict__ db,
-                                   int B, int S, int D, int C) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ dW,
+                                                          float* __restrict__ db, int B, int S, int D, int C) {
+    __shared__ float red[4][16][64];
+    const int dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl;
     const int c0 = blockIdx.y * 16;
-    if (d < D) {
-        float acc[16];
+    float acc[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float s = 0.f;
-            for (int t = 0; t < S; ++t) s += to_f32<T>(x[((long long)b * S + t) * D + d]);
-            s /= (float)S;
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    if (d < D) {
+        for (int b = grp; b < B; b += 4) {
+            const float s = token_mean(x, b, S, D, d);
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 if (c0 + c < C) acc[c] += dlogits[b * C + c0 + c] * s;
         }
+    }
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c0 + c < C) dW[(long long)(c0 + c) * D + d] = acc[c];
+    for (int c = 0; c < 16; ++c) red[grp][c][dl] = acc[c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int c = i >> 6, dd = i & 63;
+        if (c0 + c < C && blockIdx.x * 64 + dd < D)
+            dW[(long long)(c0 + c) * D + blockIdx.x * 64 + dd] = (red[0][c][dd] + red[1][c][dd]) + (red[2][c][dd] + red[3][c][dd]);
     }
     if (db && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {
         float s = 0.f;
@@ -288,8 +308,8 @@ extern "C" int hyb_head_bwd(int dtype, const void* x, const float* W, const floa
         HYB_LAUNCH_CHECK();
     }
     if (dW) {
-        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(64), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
-        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(64), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
+        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(256), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
+        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(256), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
         HYB_LAUNCH_CHECK();
     }
     return 0;
