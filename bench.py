@@ -113,15 +113,15 @@ def conv_kernel_table(args, dt_code, tdt, dev):
         lib.call("hyb_conv_pack_weight", dt_code, 1, w.data_ptr(), wpd.data_ptr(), co, ci, cop, cip, st)
         dx = torch.empty(N, H, H, cip, dtype=tdt, device=dev)
         io_bytes = float(N * H * H * (ci + co) * es)
-        rows.append(dict(kernel=f"conv{li + 1}_fwd", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_nhwc_kernel",
+        rows.append(dict(kernel=f"conv{li + 1}_fwd", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_v2_kernel",
                          ms=timeit(lambda: lib.call("hyb_conv3x3_fwd", dt_code, 0, x.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                                     part.data_ptr(), N, H, H, ci, cip, cop, st))))
-        rows.append(dict(kernel=f"conv{li + 1}_dgrad", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_nhwc_kernel",
+        rows.append(dict(kernel=f"conv{li + 1}_dgrad", composite=False, flops=flops, bytes=io_bytes, name="conv3x3_v2_kernel",
                          ms=timeit(lambda: lib.call("hyb_conv3x3_fwd", dt_code, 0, dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None,
                                                     N, H, H, co, cop, cip, st))))
         # dw = NULL: only the contraction kernel (partial slabs), without the fixed-order slab reduce
         rows.append(dict(kernel=f"conv{li + 1}_wgrad", composite=False, flops=flops, bytes=io_bytes,
-                         name="conv3x3_wgrad_kernel<%s>" % ("4" if cip % 64 == 0 else "2"),
+                         name="wgrad_v2_kernel<false>" if cip % 64 == 0 else "conv3x3_wgrad_kernel<2>",
                          ms=timeit(lambda: lib.call("hyb_conv3x3_wgrad", dt_code, 0, x.data_ptr(), dy.data_ptr(), None, N, H, H, ci, cip, co, cop,
                                                     ws.data_ptr(), nb, st))))
         del x, y, dy, ws, dx
@@ -142,11 +142,11 @@ def instep_kernel_table(args, step_fn, nsteps=8):
         ci, co = chans[li], chans[li + 1]
         flops = 2.0 * 9 * ci * co * H * H * N
         io = float(N * H * H * (ci + co) * 2)
-        specs.append((f"conv{li + 1}_fwd", 1, ci, co, "conv3x3_nhwc_kernel", flops, io))
-        specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_nhwc_kernel", flops, io))
+        specs.append((f"conv{li + 1}_fwd", 1, ci, co, "conv3x3_v2_kernel", flops, io))
+        specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_v2_kernel", flops, io))
         # the wgrad kernel is fused with the BN/ReLU/pool backward: reads x, raw conv output y, dpooled; writes the dense gradient + dW
         io_w = float(N * H * H * (ci + 2 * co) * 2 + N * (H // 2) * (H // 2) * co * 2)
-        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "conv3x3_wgrad_kernel<%s>" % ("4" if ci % 64 == 0 else "2"), flops, io_w))
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v2_kernel<true>" if ci % 64 == 0 else "conv3x3_wgrad_kernel<2>", flops, io_w))
         H //= 2
     evs = []
     for slot, sp in enumerate(specs):
@@ -174,7 +174,7 @@ def dominant_kernel(rows):
     for r in rows:
         if r.get("composite"):
             continue
-        key = r["name"] if r["name"].startswith("conv3x3_wgrad") else r["kernel"]      # fwd/dgrad instances differ per layer
+        key = r["name"] if "wgrad" in r["name"] else r["kernel"]      # fwd/dgrad template instances differ per layer
         tot.setdefault(key, []).append(r)
     key = max(tot, key=lambda k: sum(r["ms"] for r in tot[k]))
     grp = tot[key]
