@@ -165,7 +165,11 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
         return hb + lane_el + (kh * HW_ + kw) * 32 + ((q ^ sw) << 3);
     };
 
-    int tile = blockIdx.x;
+    // a workgroup walks a contiguous run of tiles (row-major inside an image): the halo rows/columns neighbouring tiles share are
+    // re-read from this XCD's L2.  The host sizes the grid so that no run is empty.
+    const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * tchunk;
+    const int tile_end = tile + tchunk < numTiles ? tile + tchunk : numTiles;
     Blk cur = decode(tile, 0);
     int hsel = 0, slot_cur = 0;
     bool after_store = false;                       // the previous block ended with a full-tile epilogue (NS stores per wave)
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
     while (true) {
         // next block: the following channel block of this tile, else the first block of this workgroup's next tile
         const bool last_cblk = cur.cblk + 1 >= nCblk;
-        const int ntile = last_cblk ? (tile + (int)gridDim.x < numTiles ? tile + (int)gridDim.x : tile) : tile;
+        const int ntile = last_cblk ? (tile + 1 < tile_end ? tile + 1 : tile) : tile;
         const Blk nxt = decode(ntile, last_cblk ? 0 : cur.cblk + 1);
         bf16* const hb_cur = hbuf + hsel * G::HBUF;
         bf16* const hb_nxt = hbuf + (hsel ^ 1) * G::HBUF;
@@ -321,8 +325,8 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
                         }
                     }
             }
-            if (tile + (int)gridDim.x >= numTiles) break;
-            tile += gridDim.x;
+            if (tile + 1 >= tile_end) break;
+            ++tile;
         }
         else after_store = false;
         cur = nxt;
@@ -354,6 +358,7 @@ int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H,
     int gx = (int)(numTiles < SLOTS ? numTiles : SLOTS);
     if (part && gx > stat_rows) gx = stat_rows;
     if (gx < 1) gx = 1;
+    gx = hyb_cdiv(numTiles, hyb_cdiv(numTiles, gx));          // contiguous runs of ceil(numTiles / gx) tiles: drop the empty ones
     const dim3 grid(gx, Cop / G::CBW);
     const void* f = part ? (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true> : (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>;
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;       // contiguous run of tiles per workgroup (L2 reuse of shared halos)
+    const int tile_end = ((int)blockIdx.x + 1) * tchunk < numTiles ? ((int)blockIdx.x + 1) * tchunk : numTiles;
+    for (int tile = blockIdx.x * tchunk; tile < tile_end; ++tile) {
         const int n = tile / (tilesX * tilesY);
         const int trem = tile - n * (tilesX * tilesY);
         const int ty0 = (trem / tilesX) * WG_TH, tx0 = (trem % tilesX) * WG_TW;
@@ -216,7 +218,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_first_kernel(const float* _
     if (k < 9 * Ci) { const int tap = k / Ci, ci = k - tap * Ci; koff = ci * WG_HP + (tap / 3) * WG_HW + (tap % 3); }
 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;       // contiguous run of tiles per workgroup (L2 reuse of shared halos)
+    const int tile_end = ((int)blockIdx.x + 1) * tchunk < numTiles ? ((int)blockIdx.x + 1) * tchunk : numTiles;
+    for (int tile = blockIdx.x * tchunk; tile < tile_end; ++tile) {
         const int n = tile / (tilesX * tilesY);
         const int trem = tile - n * (tilesX * tilesY);
         const int ty0 = (trem / tilesX) * WG_TH, tx0 = (trem % tilesX) * WG_TW;
@@ -337,7 +341,10 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nCiBlk = Cip / 64;
     const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * 64;
-    const int S = gridDim.x;
+    // contiguous run of tiles per workgroup (the host sizes the grid so that no run is empty)
+    const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tbegin = blockIdx.x * tchunk;
+    const int tcount = (tbegin + tchunk < numTiles ? tbegin + tchunk : numTiles) - tbegin;
 
     if (FUSE) {
         if (tid < 64) {
@@ -459,31 +466,28 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             }
         };
 
-        // tile sequence of this workgroup: blockIdx.x, + S, ...; the tile "after the last" is the last one again (harmless repeat)
-        int tile = blockIdx.x;
+        // tile i of this workgroup; the tiles "after the last" are the last one again (harmless repeats)
+        auto tl = [&](int i) { return w2_tile(tbegin + (i < tcount ? i : tcount - 1), tilesX, tilesY); };
         W2Unit ua[2], ub[2];
-        W2Tile t0 = w2_tile(tile, tilesX, tilesY);
+        W2Tile t0 = tl(0);
         x_dma(t0, xbuf);
         if (FUSE) { fuse_load(t0, ua); fuse_compute(t0, ua, dbuf); } else dy_dma(t0, dbuf);
-        W2Tile t1 = w2_tile(tile + S < numTiles ? tile + S : tile, tilesX, tilesY);
+        W2Tile t1 = tl(1);
         if (FUSE) fuse_load(t1, ua);                   // in flight across the barrier
         __syncthreads();                               // barrier 1: tile 0 staged
-        int it = 0;
-        for (; tile < numTiles; tile += 2 * S, it += 2) {
+        for (int i = 0; i < tcount; i += 2) {
             // even iteration: consumers read buffers 0; fill buffers 1 with t1 (registers ua), prefetch t2 into ub
             {
-                const int t2i = tile + 2 * S < numTiles ? tile + 2 * S : (tile + S < numTiles ? tile + S : tile);
-                const W2Tile t2 = w2_tile(t2i, tilesX, tilesY);
+                const W2Tile t2 = tl(i + 2);
                 x_dma(t1, xbuf + W2_XBUF);
                 if (FUSE) { fuse_load(t2, ub); fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
                 __syncthreads();
                 t1 = t2;
             }
-            if (tile + S >= numTiles) break;
+            if (i + 1 >= tcount) break;
             // odd iteration: consumers read buffers 1; fill buffers 0 with t1 (registers ub), prefetch the next into ua
             {
-                const int t2i = tile + 3 * S < numTiles ? tile + 3 * S : (tile + 2 * S < numTiles ? tile + 2 * S : tile + S);
-                const W2Tile t2 = w2_tile(t2i, tilesX, tilesY);
+                const W2Tile t2 = tl(i + 3);
                 x_dma(t1, xbuf);
                 if (FUSE) { fuse_load(t2, ua); fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
                 __syncthreads();
@@ -522,8 +526,7 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
         for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                   // barrier 1: tile 0 staged
-    int it = 0;
-    for (int tile = blockIdx.x; tile < numTiles; tile += S, ++it) {
+    for (int it = 0; it < tcount; ++it) {
         const bf16* xb = xbuf + (it & 1) * W2_XBUF;
         const bf16* db = dbuf + (it & 1) * W2_DBUF;
 #pragma unroll
@@ -608,6 +611,7 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
             int S = 256 / blocks;
             if (S > p.S) S = p.S;                          // never more slabs than the workspace query promised
             if (S > nT) S = (int)nT;
+            S = hyb_cdiv(nT, hyb_cdiv(nT, S));                // contiguous runs of ceil(nT / S) tiles: drop the empty ones
             const void* f = fz ? (const void*)wgrad_v2_kernel<true> : (const void*)wgrad_v2_kernel<false>;
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS);
             if (e != hipSuccess) return (int)e;
