@@ -440,23 +440,22 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
                 for (int e = 0; e < 8; ++e) {
                     const int c = uoct[i] * 8 + e;
                     const float sc = cst[c], sh = cst[64 + c], kk = cst[128 + c], a1 = cst[192 + c], a0 = cst[256 + c];
-                    float yf[4];
+                    float yf[4], v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) yf[j] = (float)un[i].y[j].v[e];
-                    float vmax = yf[0] * sc + sh;
-                    int am = 0;
-#pragma unroll
-                    for (int j = 1; j < 4; ++j) {
-                        const float v = yf[j] * sc + sh;
-                        if (v > vmax) { vmax = v; am = j; }
-                    }
+                    for (int j = 0; j < 4; ++j) { yf[j] = (float)un[i].y[j].v[e]; v[j] = fmaf(yf[j], sc, sh); }
+                    // the window maximum and its FIRST position in torch's scan order (0,0),(0,1),(1,0),(1,1); the flags live in scalar
+                    // masks, so the routing costs one select per position:  dyraw_j = y_j*A1 + (A0 [+ k*dy at the arg-max])
+                    const float vmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    const bool f0 = v[0] == vmax, f1 = !f0 && v[1] == vmax, f2 = !f0 && !f1 && v[2] == vmax;
+                    const bool fl[4] = {f0, f1, f2, !(f0 || f1 || f2)};
                     const float kdy = (vmax > 0.f && un[i].win_ok) ? kk * (float)un[i].g.v[e] : 0.f;
+                    const float a0k = a0 + kdy;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float base = fmaf(yf[j], a1, a0);
-                        o[j].v[e] = (bf16)(un[i].pv[j] ? (am == j ? base + kdy : base) : 0.f);
-                    }
+                    for (int j = 0; j < 4; ++j) o[j].v[e] = (bf16)fmaf(yf[j], a1, fl[j] ? a0k : a0);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!un[i].pv[j]) o[j].u = u32x4{0u, 0u, 0u, 0u};          // pixels outside the image (a select per register)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ly = 2 * uwy[i] + (j >> 1), lx = 2 * uwx[i] + (j & 1);
@@ -466,6 +465,15 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             }
         };
 
+        // End of a producer iteration.  Its vector-memory operations were issued in the order [XT halo DMAs][10 prefetch loads of
+        // the tile after][8 dyraw stores]; the images are complete once the DMAs have landed and the LDS writes are done, so the
+        // counted wait leaves the prefetch loads and the stores in flight across the barrier (a __syncthreads() would drain
+        // them and add a store round trip to every tile).
+        auto publish = [&]() {
+            if (FUSE) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
         // tile i of this workgroup; the tiles "after the last" are the last one again (harmless repeats)
         auto tl = [&](int i) { return w2_tile(tbegin + (i < tcount ? i : tcount - 1), tilesX, tilesY); };
         W2Unit ua[2], ub[2];
@@ -480,8 +488,9 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             {
                 const W2Tile t2 = tl(i + 2);
                 x_dma(t1, xbuf + W2_XBUF);
+                asm volatile("" ::: "memory");         // the DMAs stay the OLDEST vector-memory operations of the iteration (see publish)
                 if (FUSE) { fuse_load(t2, ub); fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
-                __syncthreads();
+                publish();
                 t1 = t2;
             }
             if (i + 1 >= tcount) break;
@@ -489,8 +498,9 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             {
                 const W2Tile t2 = tl(i + 3);
                 x_dma(t1, xbuf);
+                asm volatile("" ::: "memory");
                 if (FUSE) { fuse_load(t2, ua); fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
-                __syncthreads();
+                publish();
                 t1 = t2;
             }
         }
@@ -529,22 +539,37 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
     for (int it = 0; it < tcount; ++it) {
         const bf16* xb = xbuf + (it & 1) * W2_XBUF;
         const bf16* db = dbuf + (it & 1) * W2_DBUF;
+        // software pipeline over the 63 (k-step, tap) steps of the tile: the x fragment is read two steps ahead (ring of 3), the
+        // four gradient fragments of k-step j+1 are read during taps 2..5 of k-step j; the only exposed LDS latency is the
+        // first step after the tile barrier
+        auto load_a = [&](Frag<bf16>& f, int j, int c) { w2_tr(f, db + aoff[c] + j * 256, db + aoff[c] + j * 256 + W2_TW * 64); };
+        auto load_b = [&](Frag<bf16>& f, int j, int tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            // rows 2g+kh (lo) and 2g+kh+1 (hi): swizzle class = ((row >> 1) & 1) ^ (g & 1)
+            w2_tr(f, xb + bpix + (kh * W2_HW + 4 * j + kw) * 64 + boff[kw][(kh >> 1) & 1],
+                  xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * 64 + boff[kw][((kh + 1) >> 1) & 1]);
+        };
+        Frag<bf16> a[2][4], b[3];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {                  // k-step j: tile columns 4j .. 4j+3, rows 2g, 2g+1
-            Frag<bf16> a[4];
+        for (int c = 0; c < 4; ++c) load_a(a[0][c], 0, c);
+        load_b(b[0], 0, 0);
+        load_b(b[1], 0, 1);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) w2_tr(a[c], db + aoff[c] + j * 256, db + aoff[c] + j * 256 + W2_TW * 64);
+        for (int st = 0; st < 63; ++st) {
+            const int j = st / 9, tap = st % 9;
+            if (st + 2 < 63) load_b(b[(st + 2) % 3], (st + 2) / 9, (st + 2) % 9);
+            if (j < 6 && tap >= 2 && tap < 6) load_a(a[(j + 1) & 1][tap - 2], j + 1, tap - 2);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-                // rows 2g+kh (lo) and 2g+kh+1 (hi): swizzle class = ((row >> 1) & 1) ^ (g & 1)
-                const bf16* lo = xb + bpix + (kh * W2_HW + 4 * j + kw) * 64 + boff[kw][(kh >> 1) & 1];
-                const bf16* hi = xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * 64 + boff[kw][((kh + 1) >> 1) & 1];
-                Frag<bf16> b;
-                w2_tr(b, lo, hi);
+            for (int c = 0; c < 4; ++c) acc[tap][c] = mma32(a[j & 1][c], b[st % 3], acc[tap][c]);
+        }
+        // pin the interleave: after each group of 4 MFMAs the reads of two steps ahead (2 or 4 transposed reads)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[tap][c] = mma32(a[c], b, acc[tap][c]);
-            }
+        for (int st = 0; st < 63; ++st) {
+            const int j = st / 9, tap = st % 9;
+            const bool rb = st + 2 < 63, ra = j < 6 && tap >= 2 && tap < 6;
+            if (ra && rb) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else if (ra || rb) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         __syncthreads();                               // the other pair of images is complete, this pair may be overwritten
     }

@@ -7,6 +7,7 @@
 //   transposed source : element (row, r) at p[r*ld + row]   (vector loads along row, scattered LDS writes)
 // fp32 sources (the master weights) are converted to T while staging.  Token counts (M = B*T = 128..512) are
 // small, so these GEMMs are latency-bound; tiles are 64x64 or 32x32 to spread them over more CUs.
+#include <stdlib.h>
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
@@ -163,9 +164,9 @@ int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
 // (operands are L2-resident: <= 4 MB), the 4 waves of a workgroup split K (wave w takes k-steps w, w+4, ...), and the
 // partial 32x32 tiles are combined through LDS once at the end.  Grid = (No/32, Mo/32, groups).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename TC>
-__global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
-    __shared__ float red[4][32][33];
+template <typename T, typename TC, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args) {
+    __shared__ float red[NWV][32][33];
     const GemmGroup grp = args.g[blockIdx.z];
     const T* A = (const T*)grp.A;
     const T* B = (const T*)grp.B;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int R = args.R;
 #pragma unroll 4
-    for (int k0 = wave * 32; k0 < R; k0 += 128) {
+    for (int k0 = wave * 32; k0 < R; k0 += NWV * 32) {
         Frag<T> a[2], b[2];
         const bool ok = (k0 + 8 * q + 8) <= R;
 #pragma unroll
@@ -220,15 +221,17 @@ __global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmArgs args) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * q + r][j * 16 + p] = acc[i][j][r];
     __syncthreads();
-    // 1024 outputs / 256 threads: thread -> row (tid / 8), 4 consecutive columns
-    const int row = tid >> 3, c0 = (tid & 7) * 4;
+    // 1024 outputs: thread -> row, 1024 / (NWV * 64) consecutive columns; the wave partials are added in a fixed order
+    constexpr int CPT = 1024 / (NWV * 64), TPR = 32 / CPT;
+    const int row = tid / TPR, c0 = (tid % TPR) * CPT;
     const int mo = m0 + row;
     if (mo >= args.Mo) return;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CPT; ++c) {
         const int no = n0 + c0 + c;
         if (no >= args.No) continue;
         float v = (red[0][row][c0 + c] + red[1][row][c0 + c]) + (red[2][row][c0 + c] + red[3][row][c0 + c]);
+        if (NWV == 8) v += (red[4][row][c0 + c] + red[5][row][c0 + c]) + (red[6][row][c0 + c] + red[7][row][c0 + c]);
         if (grp.bias) v += grp.bias[no];
         if (args.relu) v = fmaxf(v, 0.f);
         TC* dst = C + (long long)mo * args.ldc + no;
@@ -367,9 +370,13 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
     for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr, Amask ? Amask[i] : nullptr, nullptr};
     a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), groups);
-    if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float>), grid, dim3(256), 0, st, a);
-    else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float>), grid, dim3(256), 0, st, a);
-    else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16>), grid, dim3(256), 0, st, a);
+    // few tiles (M = 128, N = 512: 64 workgroups on 256 CUs): eight waves split K to shorten the per-wave load/MFMA chain
+    static const int w8env = getenv("HYB_GEMM_W8") ? atoi(getenv("HYB_GEMM_W8")) : 1;
+    const bool w8 = w8env && (long long)grid.x * grid.y * grid.z <= 256 && R >= 256;
+    if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float, 4>), grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 4>), grid, dim3(256), 0, st, a);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
