@@ -121,7 +121,7 @@ def conv_kernel_table(args, dt_code, tdt, dev):
                                                     N, H, H, co, cop, cip, st))))
         # dw = NULL: only the contraction kernel (partial slabs), without the fixed-order slab reduce
         rows.append(dict(kernel=f"conv{li + 1}_wgrad", composite=False, flops=flops, bytes=io_bytes,
-                         name="wgrad_v2_kernel<false>" if cip % 64 == 0 else "conv3x3_wgrad_kernel<2>",
+                         name="wgrad_v2_kernel<false, %d>" % (64 if cip % 64 == 0 else 32),
                          ms=timeit(lambda: lib.call("hyb_conv3x3_wgrad", dt_code, 0, x.data_ptr(), dy.data_ptr(), None, N, H, H, ci, cip, co, cop,
                                                     ws.data_ptr(), nb, st))))
         del x, y, dy, ws, dx
@@ -146,7 +146,7 @@ def instep_kernel_table(args, step_fn, nsteps=8):
         specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_v2_kernel", flops, io))
         # the wgrad kernel is fused with the BN/ReLU/pool backward: reads x, raw conv output y, dpooled; writes the dense gradient + dW
         io_w = float(N * H * H * (ci + 2 * co) * 2 + N * (H // 2) * (H // 2) * co * 2)
-        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v2_kernel<true>" if ci % 64 == 0 else "conv3x3_wgrad_kernel<2>", flops, io_w))
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v2_kernel<true, %d>" % (64 if ci % 64 == 0 else 32), flops, io_w))
         H //= 2
     evs = []
     for slot, sp in enumerate(specs):

@@ -24,7 +24,8 @@ for k in sorted(fe, key=lambda k: -sum(fe[k])):
     fb, wb = f_avg * 1024 * 2, w_avg * 1024
     rows.append((short(k), len(fe[k]), round(f_avg), round(fb), round(w_avg), round(fb + wb)))
     if "wgrad" in k and "reduce" not in k:
-        name = "wgrad_v2_kernel<true>" if "wgrad_v2_kernel" in k else ("conv3x3_wgrad_kernel<2>" if "Li2E" in k or "<2" in k or "int, EL" in k else short(k))
+        m = re.search(r"wgrad_v2_kernel<(true|false), (\d+)>", k)
+        name = "wgrad_v2_kernel<%s, %s>" % (m.group(1), m.group(2)) if m else short(k)
         traffic[name] = {"hbm_bytes_per_launch": fb + wb, "fetch_size_kb_raw_avg": f_avg, "write_size_kb_avg": w_avg, "launches_sampled": len(fe[k]),
                          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 6 --warmup 2 "
                                    "--no-cpu-baseline --no-roofline` (real steps); FETCH_SIZE doubled per the gfx950 correction in "

@@ -100,7 +100,7 @@ def test_conv3x3_dgrad_exact(mode, ci, co, n, h, w):
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 @pytest.mark.parametrize("ci,co,n,h,w", [(32, 64, 2, 16, 16), (64, 128, 2, 11, 23), (128, 256, 1, 14, 14), (96, 96, 1, 8, 16),
                                          (32, 32, 3, 9, 9), (40, 72, 1, 8, 8), (3, 32, 2, 16, 32), (3, 64, 1, 21, 45), (1, 32, 1, 7, 5),
-                                         (64, 64, 3, 30, 58), (128, 64, 2, 56, 56), (64, 192, 5, 17, 29)])
+                                         (64, 64, 3, 30, 58), (128, 64, 2, 56, 56), (64, 192, 5, 17, 29), (32, 128, 3, 30, 58), (96, 64, 2, 20, 33)])
 def test_conv3x3_wgrad_exact(mode, ci, co, n, h, w):
     code, tdt = DT[mode]
     g = torch.Generator().manual_seed(11)

@@ -296,10 +296,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int W2_TH = 8, W2_TW = 28, W2_HW = 30, W2_HP = 10 * 30, W2_PX = 8 * 28;
-constexpr int W2_XW = (W2_HP * 8 + 63) / 64;          // x-halo DMA wave-instructions (38)
+template <int CI> struct W2X {                       // x-halo image of a CI-channel block (CI = 64 or 32)
+    static constexpr int XC = CI / 8;                 // 16-byte chunks per pixel
+    static constexpr int XW = (W2_HP * XC + 63) / 64; // DMA wave-instructions (38 / 19)
+    static constexpr int XBUF = XW * 512;             // bf16 elements per buffer
+    static constexpr size_t LDS = (size_t)2 * (XBUF + W2_PX * 64) * 2 + 5 * 64 * sizeof(float);
+    // swizzle of the chunk index: CI = 64 -> see w2_swz; CI = 32 (64-byte pixels: 4 consecutive pixels already cover all banks)
+    // only separates the two pixel rows a 32-lane read touches
+};
+template <int CI> __device__ __forceinline__ int w2x_swz(int row, int col) { return CI == 64 ? ((col & 2) | (((row >> 1) & 1) << 2)) : (((row >> 1) & 1) << 1); }
 constexpr int W2_DW = W2_PX * 8 / 64;                 // dy-tile DMA wave-instructions (28)
-constexpr int W2_XBUF = W2_XW * 512, W2_DBUF = W2_PX * 64;        // bf16 elements per buffer
-constexpr size_t W2_LDS = (size_t)2 * (W2_XBUF + W2_DBUF) * 2 + 5 * 64 * sizeof(float);
+constexpr int W2_DBUF = W2_PX * 64;                   // bf16 elements per gradient-tile buffer
 constexpr unsigned W2_OOB = 0xfffffff0u, W2_RECORDS = 0x80000000u;
 constexpr int W2_UNITS = 56 * 8;                      // FUSE work items per tile: (2x2 pooling window, 8-channel octet)
 
@@ -328,10 +335,12 @@ struct W2Unit {
     bool pv[4], win_ok;
 };
 
-template <bool FUSE>
+template <bool FUSE, int CI>
 __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ slab,
                                                        int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles,
                                                        WgradFuse fz) {
+    constexpr int XC = CI / 8, W2_XW = (W2_HP * XC + 63) / 64, W2_XBUF = W2_XW * 512;      // = W2X<CI>
+    constexpr int NCT = CI == 64 ? 4 : 2;            // co tiles per consumer wave (CI = 32: two waves split the 64 output channels)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* const xbuf = reinterpret_cast<bf16*>(smem_raw);                 // [2][W2_XBUF]
     bf16* const dbuf = xbuf + 2 * W2_XBUF;                                // [2][W2_DBUF]
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nCiBlk = Cip / 64;
-    const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * 64;
+    const int nCiBlk = Cip / CI;
+    const int co0 = (blockIdx.y / nCiBlk) * 64, ci0 = (blockIdx.y % nCiBlk) * CI;
     // contiguous run of tiles per workgroup (the host sizes the grid so that no run is empty)
     const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tbegin = blockIdx.x * tchunk;
@@ -362,15 +371,15 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
         // ================================================= producers =================================================
         const int pw = wave - 4, ptid = tid - 256;
         constexpr int XT = (W2_XW + 3) / 4, DT = (W2_DW + 3) / 4;
-        unsigned xoff[XT];
-        int xyx[XT];
+        unsigned xoff[10];                           // XT <= 10 entries used (a CI-dependent array bound captured by the lambdas below
+        int xyx[10];                                 // breaks the host-side stub instantiation in ROCm 7.2)
 #pragma unroll
         for (int k = 0; k < XT; ++k) {
             int wi = k * 4 + pw;
             if (wi > W2_XW - 1) wi = W2_XW - 1;                                     // duplicate the last piece
-            const int u = wi * 64 + lane, hp = u >> 3, cp = u & 7;
+            const int u = wi * 64 + lane, hp = u / XC, cp = u % XC;
             const int hy = hp / W2_HW, hx = hp - hy * W2_HW;
-            xoff[k] = (unsigned)(((hy * W + hx) * Cip + ((cp ^ w2_swz(hy, hx)) << 3)) * 2);
+            xoff[k] = (unsigned)(((hy * W + hx) * Cip + ((cp ^ w2x_swz<CI>(hy, hx)) << 3)) * 2);
             xyx[k] = hp < W2_HP ? ((hy << 16) | hx) : (0x7fff << 16);
         }
         auto x_dma = [&](const W2Tile& t, bf16* xb) {
@@ -509,13 +518,13 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
     }
 
     // =================================================== consumers ===================================================
-    const int cit = wave;
+    const int cit = CI == 64 ? wave : (wave & 1), coh = CI == 64 ? 0 : (wave >> 1);
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     // fragment addresses (elements).  dy tile pixel (row, col) -> (row*28 + col)*64; x halo pixel -> (row*30 + col)*64.
-    int aoff[4];
+    int aoff[NCT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int chunk = c * 2 + (pp >> 1);
+    for (int c = 0; c < NCT; ++c) {
+        const int chunk = (coh * NCT + c) * 2 + (pp >> 1);
         aoff[c] = (2 * g * W2_TW + qq) * 64 + (((chunk ^ ((qq & 2) | ((g & 1) << 2))) << 3) | ((pp & 1) << 2));
     }
     int boff[3][2];      // [kw][row parity class]: swizzled chunk offset inside the pixel
@@ -525,15 +534,15 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int sy = 0; sy < 2; ++sy)
-                boff[kw][sy] = ((chunk ^ (((kw + qq) & 2) | ((((g & 1) ^ sy)) << 2))) << 3) | ((pp & 1) << 2);
+                boff[kw][sy] = ((chunk ^ (CI == 64 ? (((kw + qq) & 2) | ((((g & 1) ^ sy)) << 2)) : (((g & 1) ^ sy) << 1))) << 3) | ((pp & 1) << 2);
     }
-    const int bpix = (2 * g * W2_HW + qq) * 64;
+    const int bpix = (2 * g * W2_HW + qq) * CI;
 
-    f32x4 acc[9][4];
+    f32x4 acc[9][NCT];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NCT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                   // barrier 1: tile 0 staged
     for (int it = 0; it < tcount; ++it) {
@@ -546,30 +555,30 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
         auto load_b = [&](Frag<bf16>& f, int j, int tap) {
             const int kh = tap / 3, kw = tap % 3;
             // rows 2g+kh (lo) and 2g+kh+1 (hi): swizzle class = ((row >> 1) & 1) ^ (g & 1)
-            w2_tr(f, xb + bpix + (kh * W2_HW + 4 * j + kw) * 64 + boff[kw][(kh >> 1) & 1],
-                  xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * 64 + boff[kw][((kh + 1) >> 1) & 1]);
+            w2_tr(f, xb + bpix + (kh * W2_HW + 4 * j + kw) * CI + boff[kw][(kh >> 1) & 1],
+                  xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * CI + boff[kw][((kh + 1) >> 1) & 1]);
         };
-        Frag<bf16> a[2][4], b[3];
+        Frag<bf16> a[2][NCT], b[3];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) load_a(a[0][c], 0, c);
+        for (int c = 0; c < NCT; ++c) load_a(a[0][c], 0, c);
         load_b(b[0], 0, 0);
         load_b(b[1], 0, 1);
 #pragma unroll
         for (int st = 0; st < 63; ++st) {
             const int j = st / 9, tap = st % 9;
             if (st + 2 < 63) load_b(b[(st + 2) % 3], (st + 2) / 9, (st + 2) % 9);
-            if (j < 6 && tap >= 2 && tap < 6) load_a(a[(j + 1) & 1][tap - 2], j + 1, tap - 2);
+            if (j < 6 && tap >= 2 && tap < 2 + NCT) load_a(a[(j + 1) & 1][tap - 2], j + 1, tap - 2);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[tap][c] = mma32(a[j & 1][c], b[st % 3], acc[tap][c]);
+            for (int c = 0; c < NCT; ++c) acc[tap][c] = mma32(a[j & 1][c], b[st % 3], acc[tap][c]);
         }
         // pin the interleave: after each group of 4 MFMAs the reads of two steps ahead (2 or 4 transposed reads)
 #pragma unroll
         for (int st = 0; st < 63; ++st) {
             const int j = st / 9, tap = st % 9;
-            const bool rb = st + 2 < 63, ra = j < 6 && tap >= 2 && tap < 6;
+            const bool rb = st + 2 < 63, ra = j < 6 && tap >= 2 && tap < 2 + NCT;
             if (ra && rb) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             else if (ra || rb) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
         }
         __syncthreads();                               // the other pair of images is complete, this pair may be overwritten
     }
@@ -579,12 +588,23 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + 4 * g + r;
+                const int co = co0 + (coh * NCT + c) * 16 + 4 * g + r;
                 out[((long long)co * 9 + tap) * Cip + ci0 + cit * 16 + (lane & 15)] = acc[tap][c][r];
             }
+}
+
+template <bool FUSE, int CI>
+int w2_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, const bf16* dy, float* slab, int N, int H, int W, int Cip, int Cop,
+              int tX, int tY, int nT, const WgradFuse& fz) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_v2_kernel<FUSE, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2X<CI>::LDS);
+    if (e != hipSuccess) return (int)e;
+    if (hook) hipEventRecord(hook->ev0, st);
+    hipLaunchKernelGGL((wgrad_v2_kernel<FUSE, CI>), grid, dim3(512), W2X<CI>::LDS, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
+    if (hook) hipEventRecord(hook->ev1, st);
+    return 0;
 }
 
 // few slabs (second-generation kernel: S = 256 / blocks): one thread per output element walks the S slabs; loads are issued
@@ -629,24 +649,24 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
     float* slab = (float*)ws;
     if constexpr (sizeof(T) == 2) {
         static const int v2 = getenv("HYB_WGRAD_V2") ? atoi(getenv("HYB_WGRAD_V2")) : 1;
-        const int blocks = (Cop / 64) * (Cip / 64);
-        if (v2 && !first && Cip % 64 == 0 && Cop % 64 == 0 && blocks <= 256 && (long long)12 * W * (Cip > Cop ? Cip : Cop) < (1ll << 29)) {
+        const int ci_blk = Cip % 64 == 0 ? 64 : 32;
+        const int blocks = (Cop / 64) * (Cip / ci_blk);
+        if (v2 && !first && Cip % 32 == 0 && Cop % 64 == 0 && blocks <= 256 && (long long)12 * W * (Cip > Cop ? Cip : Cop) < (1ll << 29)) {
             const int tX = hyb_cdiv(W, W2_TW), tY = hyb_cdiv(H, W2_TH);
             const long long nT = (long long)N * tX * tY;
             int S = 256 / blocks;
             if (S > p.S) S = p.S;                          // never more slabs than the workspace query promised
             if (S > nT) S = (int)nT;
             S = hyb_cdiv(nT, hyb_cdiv(nT, S));                // contiguous runs of ceil(nT / S) tiles: drop the empty ones
-            const void* f = fz ? (const void*)wgrad_v2_kernel<true> : (const void*)wgrad_v2_kernel<false>;
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS);
-            if (e != hipSuccess) return (int)e;
             HybProfileHook* hook2 = hyb_find_hook(2, Cip, Cop);
-            if (hook2) hipEventRecord(hook2->ev0, st);
-            if (fz) hipLaunchKernelGGL(wgrad_v2_kernel<true>, dim3(S, blocks), dim3(512), W2_LDS, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip,
-                                       Cop, tX, tY, (int)nT, *fz);
-            else hipLaunchKernelGGL(wgrad_v2_kernel<false>, dim3(S, blocks), dim3(512), W2_LDS, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip,
-                                    Cop, tX, tY, (int)nT, WgradFuse{});
-            if (hook2) hipEventRecord(hook2->ev1, st);
+            const WgradFuse fzv = fz ? *fz : WgradFuse{};
+            const dim3 grid2(S, blocks);
+            int lrc = 0;
+            if (ci_blk == 64) lrc = fz ? w2_launch<true, 64>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv)
+                                       : w2_launch<false, 64>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
+            else lrc = fz ? w2_launch<true, 32>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv)
+                          : w2_launch<false, 32>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
+            if (lrc) return lrc;
             HYB_LAUNCH_CHECK();
             if (!dw) return 0;
             if (S <= 64) hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3(hyb_cdiv(p.per_slab, 256)), dim3(256), 0, st, slab, dw, S, Co, Ci, Cip, p.per_slab);
