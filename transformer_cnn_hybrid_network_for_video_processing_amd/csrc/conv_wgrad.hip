@@ -282,9 +282,9 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // -----------------------------------------------------------------------------------------------------------------
 // Second generation (bf16, Cip % 64 == 0, Cop % 64 == 0): one 8-wave workgroup per CU owns a 64 co x 64 ci x 9 tap block and
 // walks 8 x 28-pixel tiles (7 k-steps of 32 pixels; 28 | 224/2^k).  The waves are specialised:
-//   * waves 0-3 (consumers, one per SIMD): the contraction.  Wave = 64 co x 16 ci x 9 taps (36 accumulator tiles); fragments are
+//   * CW consumer waves (4 = one per SIMD, or 8): the contraction.  At CW = 4, wave = 64 co x 16 ci x 9 taps (36 accumulator tiles); fragments are
 //     transposed reads (ds_read_b64_tr_b16) of the two LDS tile images;
-//   * waves 4-7 (producers, one per SIMD, sharing it with a consumer): fill the OTHER pair of tile images meanwhile.  The x halo
+//   * PW producer waves (4 or 8, sharing the SIMDs with the consumers): fill the OTHER pair of tile images meanwhile.  The x halo
 //     is written by buffer_load ... lds (zero padding = out-of-range lanes, see conv_v2.hip).  FUSE: the gradient tile
 //     (BatchNorm/ReLU/MaxPool backward from y, dpooled and per-channel constants) is computed on the vector units, which are
 //     otherwise idle under the consumers' MFMAs, and its dense copy dyraw is written once for the dgrad conv;  plain: the
@@ -335,12 +335,14 @@ struct W2Unit {
     bool pv[4], win_ok;
 };
 
-template <bool FUSE, int CI>
-__global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ slab,
+template <bool FUSE, int CI, int CW, int PW>
+__global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ slab,
                                                        int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles,
                                                        WgradFuse fz) {
     constexpr int XC = CI / 8, W2_XW = (W2_HP * XC + 63) / 64, W2_XBUF = W2_XW * 512;      // = W2X<CI>
-    constexpr int NCT = CI == 64 ? 4 : 2;            // co tiles per consumer wave (CI = 32: two waves split the 64 output channels)
+    // CW consumer waves (4: one per SIMD, 8: two per SIMD) share the (CI / 16) x 4 output tiles of the block: NCT co tiles per wave
+    constexpr int NCT = 4 * (CI / 16) / CW, NCIT = CI / 16;
+    static_assert(NCT >= 1 && NCT * CW == 4 * NCIT, "consumer tiling");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* const xbuf = reinterpret_cast<bf16*>(smem_raw);                 // [2][W2_XBUF]
     bf16* const dbuf = xbuf + 2 * W2_XBUF;                                // [2][W2_DBUF]
@@ -367,15 +369,16 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
     }
     __syncthreads();                                   // barrier 0: constants visible
 
-    if (wave >= 4) {
+    if (wave >= CW) {
         // ================================================= producers =================================================
-        const int pw = wave - 4, ptid = tid - 256;
-        constexpr int XT = (W2_XW + 3) / 4, DT = (W2_DW + 3) / 4;
+        const int pw = wave - CW, ptid = tid - CW * 64;
+        constexpr int XT = (W2_XW + PW - 1) / PW, DT = (W2_DW + PW - 1) / PW;
+        constexpr int NU = 512 / (PW * 64);            // FUSE work items per producer thread (448 units over PW * 64 threads)
         unsigned xoff[10];                           // XT <= 10 entries used (a CI-dependent array bound captured by the lambdas below
         int xyx[10];                                 // breaks the host-side stub instantiation in ROCm 7.2)
 #pragma unroll
         for (int k = 0; k < XT; ++k) {
-            int wi = k * 4 + pw;
+            int wi = k * PW + pw;
             if (wi > W2_XW - 1) wi = W2_XW - 1;                                     // duplicate the last piece
             const int u = wi * 64 + lane, hp = u / XC, cp = u % XC;
             const int hy = hp / W2_HW, hx = hp - hy * W2_HW;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             for (int k = 0; k < XT; ++k) {
                 const int gy = t.ty0 - 1 + (xyx[k] >> 16), gx = t.tx0 - 1 + (xyx[k] & 0xffff);
                 const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                int wi = k * 4 + pw;
+                int wi = k * PW + pw;
                 if (wi > W2_XW - 1) wi = W2_XW - 1;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(xb + wi * 512), 16, valid ? xoff[k] : W2_OOB, 0, 0, 0);
             }
@@ -399,7 +402,8 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             const __amdgpu_buffer_rsrc_t rs = hyb_rsrc(dy + base, W2_RECORDS);
 #pragma unroll
             for (int k = 0; k < DT; ++k) {
-                const int wi = k * 4 + pw;                                          // 28 pieces = 4 waves x 7
+                int wi = k * PW + pw;
+                if (wi > W2_DW - 1) wi = W2_DW - 1;
                 const int u = wi * 64 + lane, px = u >> 3, cp = u & 7;
                 const int ly = px / W2_TW, lx = px - ly * W2_TW;
                 const bool valid = (t.ty0 + ly < H) && (t.tx0 + lx < W);
@@ -407,13 +411,13 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(db + wi * 512), 16, valid ? off : W2_OOB, 0, 0, 0);
             }
         };
-        // FUSE work items of this thread: units ptid and ptid + 256 (the second is a repeat of unit 447 for ptid >= 192: same
+        // FUSE work items of this thread: units ptid + i * PW * 64 (indices past 447 repeat unit 447: same
         // values to the same addresses).  Branch-free: invalid lanes go out of the descriptors' range.
-        int uoct[2], uwy[2], uwx[2];
-        unsigned yoff[2][4], goff[2];
+        int uoct[NU], uwy[NU], uwx[NU];
+        unsigned yoff[NU][4], goff[NU];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int u = ptid + i * 256;
+        for (int i = 0; i < NU; ++i) {
+            int u = ptid + i * PW * 64;
             if (u > W2_UNITS - 1) u = W2_UNITS - 1;
             uoct[i] = u & 7;
             const int win = u >> 3;
@@ -423,13 +427,13 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             goff[i] = (unsigned)(((uwy[i] * (W >> 1) + uwx[i]) * Cop + 8 * uoct[i]) * 2);
         }
         const bool writer = FUSE && fz.dyraw_out && ci0 == 0;
-        auto fuse_load = [&](const W2Tile& t, W2Unit (&un)[2]) {
+        auto fuse_load = [&](const W2Tile& t, W2Unit (&un)[NU]) {
             const int Ho = H >> 1, Wo = W >> 1;
             const long long ybase = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
             const __amdgpu_buffer_rsrc_t y_rs = hyb_rsrc((const bf16*)fz.y + ybase, W2_RECORDS);
             const __amdgpu_buffer_rsrc_t g_rs = hyb_rsrc((const bf16*)fz.dp + ((long long)(t.n * Ho + (t.ty0 >> 1)) * Wo + (t.tx0 >> 1)) * Cop + co0, W2_RECORDS);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NU; ++i) {
                 un[i].win_ok = ((t.ty0 >> 1) + uwy[i]) < Ho && ((t.tx0 >> 1) + uwx[i]) < Wo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -439,11 +443,11 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
                 un[i].g.u = __builtin_amdgcn_raw_buffer_load_b128(g_rs, un[i].win_ok ? goff[i] : W2_OOB, 0, 0);
             }
         };
-        auto fuse_compute = [&](const W2Tile& t, W2Unit (&un)[2], bf16* db) {
+        auto fuse_compute = [&](const W2Tile& t, W2Unit (&un)[NU], bf16* db) {
             const long long ybase = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
             const __amdgpu_buffer_rsrc_t o_rs = hyb_rsrc((bf16*)fz.dyraw_out + ybase, writer ? W2_RECORDS : 0u);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NU; ++i) {
                 union { u32x4 u; bf16x8 v; } o[4];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -479,13 +483,14 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
         // counted wait leaves the prefetch loads and the stores in flight across the barrier (a __syncthreads() would drain
         // them and add a store round trip to every tile).
         auto publish = [&]() {
-            if (FUSE) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+            if (FUSE && NU == 2) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");         // 2 x (5 loads + 4 stores)
+            else if (FUSE) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         };
         // tile i of this workgroup; the tiles "after the last" are the last one again (harmless repeats)
         auto tl = [&](int i) { return w2_tile(tbegin + (i < tcount ? i : tcount - 1), tilesX, tilesY); };
-        W2Unit ua[2], ub[2];
+        W2Unit ua[NU], ub[NU];
         W2Tile t0 = tl(0);
         x_dma(t0, xbuf);
         if (FUSE) { fuse_load(t0, ua); fuse_compute(t0, ua, dbuf); } else dy_dma(t0, dbuf);
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
     }
 
     // =================================================== consumers ===================================================
-    const int cit = CI == 64 ? wave : (wave & 1), coh = CI == 64 ? 0 : (wave >> 1);
+    const int cit = wave % NCIT, coh = wave / NCIT;           // this wave: ci tile cit, co tiles coh*NCT .. coh*NCT + NCT-1
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     // fragment addresses (elements).  dy tile pixel (row, col) -> (row*28 + col)*64; x halo pixel -> (row*30 + col)*64.
     int aoff[NCT];
@@ -596,15 +601,26 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const bf16* __restrict__ 
             }
 }
 
+template <bool FUSE, int CI, int CW, int PW>
+int w2_launch_cw(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, const bf16* dy, float* slab, int N, int H, int W, int Cip, int Cop,
+                 int tX, int tY, int nT, const WgradFuse& fz) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_v2_kernel<FUSE, CI, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2X<CI>::LDS);
+    if (e != hipSuccess) return (int)e;
+    if (hook) hipEventRecord(hook->ev0, st);
+    hipLaunchKernelGGL((wgrad_v2_kernel<FUSE, CI, CW, PW>), grid, dim3((CW + PW) * 64), W2X<CI>::LDS, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
+    if (hook) hipEventRecord(hook->ev1, st);
+    return 0;
+}
 template <bool FUSE, int CI>
 int w2_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, const bf16* dy, float* slab, int N, int H, int W, int Cip, int Cop,
               int tX, int tY, int nT, const WgradFuse& fz) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_v2_kernel<FUSE, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2X<CI>::LDS);
-    if (e != hipSuccess) return (int)e;
-    if (hook) hipEventRecord(hook->ev0, st);
-    hipLaunchKernelGGL((wgrad_v2_kernel<FUSE, CI>), grid, dim3(512), W2X<CI>::LDS, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
-    if (hook) hipEventRecord(hook->ev1, st);
-    return 0;
+    // consumer x producer waves per workgroup: 4x4 (one of each per SIMD) or 8x8 (two of each per SIMD).  Measured in one call
+    // (fused, config 2): the HBM-bound 32-channel-block stage gains from 8x8 (127 -> 110 us), the 64-channel-block stages lose
+    // (94 -> 110 us: 128 VGPRs spill the 36-tile accumulators' helpers); 8 consumers + 4 producers is never best when fused.
+    static const int env = getenv("HYB_WGRAD_WAVES") ? atoi(getenv("HYB_WGRAD_WAVES")) : 0;
+    const int cfg = env ? env : (CI == 32 ? 88 : 44);
+    if (cfg == 88) return w2_launch_cw<FUSE, CI, 8, 8>(grid, hook, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
+    return w2_launch_cw<FUSE, CI, 4, 4>(grid, hook, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
 }
 
 // few slabs (second-generation kernel: S = 256 / blocks): one thread per output element walks the S slabs; loads are issued
