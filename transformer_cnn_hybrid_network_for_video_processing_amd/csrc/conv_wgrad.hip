@@ -335,6 +335,13 @@ struct W2Unit {
     bool pv[4], win_ok;
 };
 
+// the prefetch loads of the tile after next must be ISSUED before the vector work on the next tile (the compiler otherwise sinks
+// them behind it, next to their first use, and their HBM latency lands on the critical path of the following iteration)
+#ifdef HYB_NO_KEEP_EARLY
+#define W2_KEEP_EARLY
+#else
+#define W2_KEEP_EARLY asm volatile("" ::: "memory")
+#endif
 template <bool FUSE, int CI, int CW, int PW>
 __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ slab,
                                                        int N, int H, int W, int Cip, int Cop, int tilesX, int tilesY, int numTiles,
@@ -503,7 +510,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
                 const W2Tile t2 = tl(i + 2);
                 x_dma(t1, xbuf + W2_XBUF);
                 asm volatile("" ::: "memory");         // the DMAs stay the OLDEST vector-memory operations of the iteration (see publish)
-                if (FUSE) { fuse_load(t2, ub); fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
+                if (FUSE) { fuse_load(t2, ub); W2_KEEP_EARLY; fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
                 publish();
                 t1 = t2;
             }
@@ -513,7 +520,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
                 const W2Tile t2 = tl(i + 3);
                 x_dma(t1, xbuf);
                 asm volatile("" ::: "memory");
-                if (FUSE) { fuse_load(t2, ua); fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
+                if (FUSE) { fuse_load(t2, ua); W2_KEEP_EARLY; fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
                 publish();
                 t1 = t2;
             }
