@@ -186,6 +186,13 @@ __device__ __forceinline__ bool rows_reduce_1024(const float* __restrict__ part,
     float a0 = 0.f, a1 = 0.f;
     if (i < n) {
         int g = grp;
+        // eight independent loads in flight per thread (these kernels are one or two workgroups: pure latency), fixed add order
+        for (; g + 7 * 32 < G; g += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(long long)(g + j * 32) * n + i];
+            a0 += v[0]; a1 += v[1]; a0 += v[2]; a1 += v[3]; a0 += v[4]; a1 += v[5]; a0 += v[6]; a1 += v[7];
+        }
         for (; g + 32 < G; g += 64) { a0 += part[(long long)g * n + i]; a1 += part[(long long)(g + 32) * n + i]; }
         if (g < G) a0 += part[(long long)g * n + i];
     }
