@@ -260,7 +260,17 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (oc < OCT) {
         const T* src = x + (long long)n * HW * Cp + oc * 8;
-        for (int p = grp; p < HW; p += 8) {
+        int p = grp;
+        for (; p + 3 * 8 < HW; p += 4 * 8) {              // four independent loads in flight, additions in pixel order
+            Vec8<T> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u].load(src + (long long)(p + u * 8) * Cp);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[u].get(j);
+        }
+        for (; p < HW; p += 8) {
             Vec8<T> v;
             v.load(src + (long long)p * Cp);
 #pragma unroll
