@@ -143,6 +143,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
         }
 }
 
+// Weight (+ bias) gradients of up to 6 Linear layers with DIFFERENT shapes in one launch (the six matrices of an encoder layer):
+//   dW_g[n][k] = sum_m dym_g[m][n] * x_g[m][k],   db_g[n] = sum_m dym_g[m][n],   dym_g = dy_g * (mask_g > 0) (mask optional).
+// Flat grid: workgroup -> (group, 64x64 tile) through the groups' tile offsets.
+struct DwGroup {
+    const void* dy; const void* mask; const void* x;
+    float* dW; float* db;
+    int N, K, lddy, ldx;       // dW is [N][K]; dy rows have lddy elements, x rows ldx
+    int tiles_x, tile_begin;
+};
+struct DwArgs { DwGroup g[6]; int ngroups, M; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
+    constexpr int BM = 64, WM = 32, MT = 2;
+    __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) T Bs[BM * LDS_ROW];
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (i < args.ngroups && (int)blockIdx.x >= args.g[i].tile_begin) gi = i;
+    const DwGroup grp = args.g[gi];
+    const int local = blockIdx.x - grp.tile_begin;
+    const int bx = local % grp.tiles_x, by = local / grp.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by * BM, n0 = bx * BM;                 // m: rows of dW (N), n: columns of dW (K)
+    const int p = lane & 15, q = lane >> 4;
+    f32x4 acc[MT][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    for (int r0 = 0; r0 < args.M; r0 += BK) {
+        __syncthreads();
+        stage_tile<T, T, true, BM>((const T*)grp.dy, (const T*)grp.mask, grp.lddy, m0, grp.N, r0, args.M, As, tid);
+        stage_tile<T, T, true, BM>((const T*)grp.x, (const T*)nullptr, grp.ldx, n0, grp.K, r0, args.M, Bs, tid);
+        __syncthreads();
+        if (grp.db && bx == 0 && tid < BM) {
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) csum += to_f32<T>(As[tid * LDS_ROW + r]);
+        }
+        Frag<T> a[MT], b[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) frag_load(a[i], As + (wm * WM + i * 16 + p) * LDS_ROW + 8 * q);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) frag_load(b[j], Bs + (wn * WM + j * 16 + p) * LDS_ROW + 8 * q);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+    }
+    if (grp.db && bx == 0 && tid < BM && m0 + tid < grp.N) grp.db[m0 + tid] = csum;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int no = n0 + wn * WM + j * 16 + p;
+            if (no >= grp.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = m0 + wm * WM + i * 16 + 4 * q + r;
+                if (mo < grp.N) grp.dW[(long long)mo * grp.K + no] = acc[i][j][r];
+            }
+        }
+}
+
 template <typename T, typename TA, typename TB, typename TC, bool TRANS_A, bool TRANS_B>
 int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
     const long long tiles64 = (long long)hyb_cdiv(a.Mo, 64) * hyb_cdiv(a.No, 64) * groups;
@@ -393,6 +461,26 @@ int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const vo
     if (dtype == HYB_F32) return launch_gemm<float, float, float, float, true, true>(a, groups, st);
     if (dtype == HYB_BF16) return launch_gemm<bf16, bf16, bf16, float, true, true>(a, groups, st);
     return HYB_E_ARG;
+}
+
+// Internal: weight + bias gradients of up to 6 Linear layers of different shapes in one launch (see gemm_dw_multi_kernel).
+int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
+                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st) {
+    if (groups < 1 || groups > 6 || M < 1) return HYB_E_ARG;
+    DwArgs a{};
+    int tiles = 0;
+    for (int i = 0; i < groups; ++i) {
+        if (N[i] % 8 != 0 || K[i] % 8 != 0) return HYB_E_ARG;
+        const int tx = hyb_cdiv(K[i], 64), ty = hyb_cdiv(N[i], 64);
+        a.g[i] = DwGroup{dy[i], mask ? mask[i] : nullptr, x[i], dW[i], db ? db[i] : nullptr, N[i], K[i], lddy[i], ldx[i], tx, tiles};
+        tiles += tx * ty;
+    }
+    a.ngroups = groups; a.M = M;
+    if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(tiles), dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(tiles), dim3(256), 0, st, a);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
 }
 
 // Internal: convert up to 8 fp32 weight matrices to T (plain + transposed copies) in one launch.

@@ -9,6 +9,8 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
                         const int* ldt, hipStream_t st);
+int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
+                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* probs, int B, int S, int D, int H, float p_drop,
@@ -242,6 +244,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
     void* gin[2] = {ws + 6 * md, ws + 7 * md};
     const size_t big = align256((size_t)M * (Hid > D ? Hid : D) * es);
     void* dh = ws + 8 * md;             // d(hmid)
+    void* g1b = ws + 8 * md + big;      // d(LN1 input): its own buffer so that all six dW inputs of a layer are alive at its end
 
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
@@ -257,32 +260,33 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         // FFN second Linear: dX = g1 . W2 (pre-transposed copy), dW/db in one launch
         { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {dh};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
-        { const void* dy_[1] = {g1}; float* dW_[1] = {G[10]}; float* db_[1] = {G[11]};
-          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, nullptr, base + lay.hmid, dW_, db_, M, D, Hid, D, Hid, st)); }
         // FFN first Linear (+ReLU): the mask (hmid > 0) is applied inside the GEMM loaders
         { const void* A_[1] = {dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
-        { const void* dy_[1] = {dh}; const void* mk_[1] = {base + lay.hmid}; float* dW_[1] = {G[8]}; float* db_[1] = {G[9]};
-          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, mk_, base + lay.x1, dW_, db_, M, Hid, D, Hid, D, st)); }
         // LN1 + residual
-        HYB_TRY(hyb_ln_residual_bwd(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1, gx, 0, G[12], G[13], M, D, 1.0f, 0.f,
+        HYB_TRY(hyb_ln_residual_bwd(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1b, gx, 0, G[12], G[13], M, D, 1.0f, 0.f,
                                     0ull, stream));
         // output projection
-        { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
+        { const void* A_[1] = {g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
-        { const void* dy_[1] = {g1}; float* dW_[1] = {G[6]}; float* db_[1] = {G[7]};
-          HYB_TRY(hyb_linear_dw_grouped(dtype, 1, dy_, nullptr, base + lay.attn, dW_, db_, M, D, D, D, D, st)); }
         // attention core: d(q|k|v) packed [M][3D]
         HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
                                          attn_seed(seed, i), st));
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM, one grouped dW/db launch
         { const void* A_[1] = {dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }
-        { const char* dq_ = (const char*)dqkv; const char* qk_ = base + lay.qkv;
-          const void* dy_[3] = {dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
-          const void* mk_[3] = {qk_, qk_ + (size_t)D * es, qk_ + 2 * (size_t)D * es};
-          float* dW_[3] = {G[0], G[2], G[4]}; float* db_[3] = {G[1], G[3], G[5]};
-          HYB_TRY(hyb_linear_dw_grouped(dtype, 3, dy_, mk_, base + lay.x_in, dW_, db_, M, D, D, 3 * D, D, st)); }
+        // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches)
+        {
+            const char* dq_ = (const char*)dqkv; const char* qk_ = base + lay.qkv;
+            const void* dy_[6] = {g1, dh, g1b, dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
+            const void* mk_[6] = {nullptr, base + lay.hmid, nullptr, qk_, qk_ + (size_t)D * es, qk_ + 2 * (size_t)D * es};
+            const void* x_[6] = {base + lay.hmid, base + lay.x1, base + lay.attn, base + lay.x_in, base + lay.x_in, base + lay.x_in};
+            float* dW_[6] = {G[10], G[8], G[6], G[0], G[2], G[4]};
+            float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
+            const int N_[6] = {D, Hid, D, D, D, D}, K_[6] = {Hid, D, D, D, D, D};
+            const int lddy_[6] = {D, Hid, D, 3 * D, 3 * D, 3 * D}, ldx_[6] = {Hid, D, D, D, D, D};
+            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st));
+        }
         gA = gx;
     }
     return 0;
