@@ -121,6 +121,71 @@ def test_conv3x3_wgrad_exact(mode, ci, co, n, h, w):
     assert torch.equal(dw.cpu(), want)
 
 
+def _fuzz_shapes(seed, count, cis, cos):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(count):
+        ci, co = rnd.choice(cis), rnd.choice(cos)
+        n = rnd.choice([1, 2, 3, 5])
+        h = rnd.choice([1, 3, 4, 7, 8, 9, 27, 28, 29, 31, 57])
+        w = rnd.choice([1, 2, 5, 27, 28, 29, 55, 56, 57, 60, 85])
+        out.append((ci, co, n, h, w))
+    return out
+
+
+@pytest.mark.parametrize("ci,co,n,h,w", _fuzz_shapes(101, 10, [32, 64, 128], [32, 64, 128, 256]))
+def test_conv3x3_fwd_stats_dgrad_exact_fuzz(ci, co, n, h, w):
+    """Seeded shape fuzz of the asynchronous bf16 conv kernel (tile edges, 1-pixel images, several tiles per workgroup, all channel
+    configurations): forward + statistics, and dgrad through the same kernel with mode-1 weights."""
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(ci * 7 + co * 3 + h * 11 + w)
+    x = sparse_int((n, ci, h, w), g, 0, 2, 0.5)
+    wt = sparse_int((co, ci, 3, 3), g, -2, 2, 0.15)
+    xr = x.clone().requires_grad_(True)
+    want = F.conv2d(xr, wt, padding=1)
+    dy = sparse_int((n, co, h, w), g, -1, 1, 0.4)
+    want.backward(dy)
+    assert want.abs().max() <= 256 and xr.grad.abs().max() <= 256
+    cip, cop = pad32(ci), pad32(co)
+    wp = torch.empty(cop * 9 * cip, dtype=tdt, device="cuda")
+    wpd = torch.empty(cip * 9 * cop, dtype=tdt, device="cuda")
+    wd = wt.cuda().contiguous()
+    L().call("hyb_conv_pack_weight", code, 0, wd.data_ptr(), wp.data_ptr(), co, ci, cop, cip, st())
+    L().call("hyb_conv_pack_weight", code, 1, wd.data_ptr(), wpd.data_ptr(), co, ci, cop, cip, st())
+    xin = to_nhwc(x, code, tdt, cip)
+    y = torch.full((n, h, w, cop), 7.0, dtype=tdt, device="cuda")
+    stats = torch.zeros(2, cop, device="cuda")
+    part = torch.empty(L().query("hyb_conv_stats_workspace", cop), dtype=torch.uint8, device="cuda")
+    L().call("hyb_conv3x3_fwd", code, 0, xin.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), part.data_ptr(), n, h, w, ci, cip, cop, st())
+    assert torch.equal(to_nchw(y, code, co).cpu(), want.detach())
+    assert torch.equal(stats[0, :co].cpu(), want.detach().sum(dim=(0, 2, 3)))
+    assert torch.equal(stats[1, :co].cpu(), (want.detach() * want.detach()).sum(dim=(0, 2, 3)))
+    dyn = to_nhwc(dy, code, tdt, cop)
+    dx = torch.empty(n, h, w, cip, dtype=tdt, device="cuda")
+    L().call("hyb_conv3x3_fwd", code, 0, dyn.data_ptr(), wpd.data_ptr(), dx.data_ptr(), None, None, n, h, w, co, cop, cip, st())
+    assert torch.equal(to_nchw(dx, code, ci).cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("ci,co,n,h,w", _fuzz_shapes(202, 10, [32, 64, 96, 128], [64, 128, 192]))
+def test_conv3x3_wgrad_exact_fuzz(ci, co, n, h, w):
+    """Seeded shape fuzz of the warp-specialised bf16 weight-gradient kernel (both channel-block widths, tile edges, odd tile counts)."""
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(ci * 5 + co + h * 13 + w)
+    x = sparse_int((n, ci, h, w), g, 0, 2, 0.5)
+    dy = sparse_int((n, co, h, w), g, -2, 2, 0.3)
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x, wt, padding=1).backward(dy)
+    cip, cop = pad32(ci), pad32(co)
+    xin = to_nhwc(x, code, tdt, cip)
+    dyn = to_nhwc(dy, code, tdt, cop)
+    dw = torch.full((co, ci, 3, 3), 3.0, device="cuda")
+    nb = L().query("hyb_conv3x3_wgrad_workspace", 0, n, h, w, cip, cop)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    L().call("hyb_conv3x3_wgrad", code, 0, xin.data_ptr(), dyn.data_ptr(), dw.data_ptr(), n, h, w, ci, cip, co, cop, ws.data_ptr(), nb, st())
+    assert torch.equal(dw.cpu(), wt.grad)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 @pytest.mark.parametrize("M,N,K,relu", [(128, 512, 512, 1), (128, 2048, 512, 1), (128, 512, 2048, 0), (5, 24, 40, 0), (37, 72, 256, 1),
                                         (512, 768, 768, 0), (128, 512, 256, 0)])
