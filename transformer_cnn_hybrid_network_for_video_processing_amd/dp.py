@@ -7,37 +7,45 @@ only parameter gradients (6.83 M fp32 = 27.3 MB at BASELINE config 2) are exchan
 statistics stay per-rank (the reference has no SyncBN), so W ranks compute "W independent batch-B
 BatchNorm forward/backward passes, gradients averaged".
 
-Buckets are filled in backward-readiness order (head -> encoder -> conv4 -> ... -> conv1).  A bucket's
-all-reduce is launched asynchronously from the autograd hook of its last-arriving gradient, so the
-encoder bucket (25 MB of the 27 MB) travels while the conv backward -- >99 % of backward FLOPs -- is
-still running.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a 25 MB ring all-reduce is
-~0.3 ms, far below the conv backward it hides under, so two or three large buckets beat many small ones.
+Buckets are filled in backward-readiness order (head -> encoder -> token projection -> conv4 -> ... -> conv1) and are cut
+where readiness changes: a bucket is closed when it is full (``bucket_bytes``) and also when the next parameter belongs to
+another top-level submodule while the bucket already holds ``min_bucket_bytes``.  At BASELINE config 2 that gives
+[head + encoder, 16 MB] [rest of the encoder, 9 MB] [token projection + conv4, 1.7 MB] [conv3..conv1, 0.4 MB]: the first
+two are complete as soon as the encoder backward returns and travel under the whole CNN backward (>99 % of the backward
+FLOPs, ~0.9 ms), the third under conv3..conv1; only the last 0.4 MB is exposed.  (One 32 MB bucket -- the whole model --
+would start its all-reduce only after the last gradient and overlap nothing.)  A bucket's all-reduce is launched
+asynchronously from the autograd hook of its last-arriving gradient.  xGMI is point-to-point (7 links x ~153 GB/s per
+GPU): a 25 MB ring all-reduce is ~0.3 ms.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, module, process_group=None, bucket_bytes=32 << 20, broadcast=True):
+    def __init__(self, module, process_group=None, bucket_bytes=16 << 20, min_bucket_bytes=1 << 20, broadcast=True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        # the named_parameters order, reversed, is ~ the order gradients become ready in backward
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
         if broadcast:
             self.broadcast_state()
-        # reverse registration order ~ the order gradients become ready in backward
-        order = list(reversed(self.params))
+        # NCCL/RCCL can average inside the collective; gloo cannot (sum, then scale)
+        self._avg = dist.get_backend(process_group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
         self.buckets = []            # each: dict(params, flat, views, pending, work)
-        cur, cur_bytes = [], 0
-        for p in order:
+        cur, cur_bytes, cur_top = [], 0, None
+        for name, p in reversed(named):
             nb = p.numel() * 4
-            if cur and cur_bytes + nb > bucket_bytes:
+            top = name.split(".", 1)[0]
+            if cur and (cur_bytes + nb > bucket_bytes or (top != cur_top and cur_bytes >= min_bucket_bytes)):
                 self._close_bucket(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
+            cur_top = top
         if cur:
             self._close_bucket(cur)
         self._bucket_of = {}
@@ -67,7 +75,11 @@ class GradAllReducer:
         if b["pending"] == 0:
             grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in b["params"]]
             torch._foreach_copy_(b["views"], grads)
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["work"] = self._launch(b)
+
+    def _launch(self, b):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        return dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def finalize(self):
         """Wait for the in-flight buckets, average, and write the result back into p.grad."""
@@ -78,11 +90,12 @@ class GradAllReducer:
                     # some gradients of this bucket never arrived (unused parameters): reduce what is there
                     grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in b["params"]]
                     torch._foreach_copy_(b["views"], grads)
-                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b["work"] = self._launch(b)
                 else:
                     continue
             b["work"].wait()
-            b["flat"].mul_(inv)
+            if not self._avg:
+                b["flat"].mul_(inv)
             for q, v in zip(b["params"], b["views"]):
                 if q.grad is None:
                     q.grad = v.clone()
