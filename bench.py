@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["B"], help="clips per GPU")
     ap.add_argument("--frames", type=int, default=CFG["T"])
     ap.add_argument("--size", type=int, default=CFG["H"])
+    ap.add_argument("--optimizer", default="hybrid", choices=["hybrid", "torch"],
+                    help="AdamW implementation of the step: this repo's one-launch kernel (SURVEY 8f-2) or torch.optim.AdamW(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -257,10 +259,13 @@ def main():
                                    dropout=0.0, compute_dtype=args.dtype).to(dev)
     model.train()
     crit = P.HybridCrossEntropyLoss()
-    try:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)      # stock torch optimizer, single fused multi-tensor kernel
-    except Exception:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    if args.optimizer == "hybrid":
+        opt = P.HybridAdamW(model.parameters(), lr=1e-3)                      # same update as torch.optim.AdamW, one launch
+    else:
+        try:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)  # stock torch optimizer, fused multi-tensor kernels
+        except Exception:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     reducer = GradAllReducer(model) if world > 1 else None
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)          # rank r seeds its own clips
@@ -313,7 +318,9 @@ def main():
             "config": {"workload": f"config 2: clips [{args.batch},{args.frames},3,{args.size},{args.size}] per GPU, CNN 32-64-128-256 + "
                                    f"2-layer transformer d=512 h=8 hid=2048, 8 classes",
                        "global_batch": args.batch * world, "frames": args.frames,
-                       "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw", "parallelism": f"dp{world}",
+                       "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw",
+                       "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
+                       "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)"},
             "final_loss": final_loss,
         }

@@ -225,6 +225,15 @@ int hyb_cross_entropy_fwd(const float* logits, const long long* target, float* l
 int hyb_cross_entropy_bwd(const float* logits, const long long* target, const float* dloss /* [1] */,
                           float* dlogits, int B, int C, void* stream);
 
+/* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
+ * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
+ * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]
+ * elements); state tensors are caller-owned and must be zero before step 1.  Hyper-parameters are doubles (Python floats):
+ * 1 - beta etc. are formed in double and rounded to fp32 once, like torch does. */
+int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

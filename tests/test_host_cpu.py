@@ -56,6 +56,7 @@ def test_argument_checks_fail_without_a_device(built):
     assert built.raw("hyb_linear_fwd")(1, None, 8, None, None, None, 4, 8, 8, 0, None) == -1
     assert built.raw("hyb_attention_fwd")(1, None, None, None, None, None, None, 1, 4, 8, 2, 0.0, 0, None) == -1
     assert built.raw("hyb_cross_entropy_fwd")(None, None, None, 1, 2, None) == -1
+    assert built.raw("hyb_adamw_step")(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None) == -1
     with pytest.raises(RuntimeError, match="argument check"):
         built.call("hyb_gap_fwd", 1, None, None, 1, 1, 32, None)
     # workspace / size queries are pure host functions
@@ -111,6 +112,9 @@ def test_product_path_refuses_cpu_tensors():
         P.TransformerEncoder(8, 16, 1, 2, 0.0)(torch.rand(1, 4, 8), None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         P.HybridCrossEntropyLoss()(torch.rand(2, 3), torch.tensor([0, 1]))
+    w = torch.nn.Parameter(torch.rand(4)); w.grad = torch.rand(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.HybridAdamW([w]).step()
     with pytest.raises(ValueError):
         m(torch.rand(3, 16, 16))
 

@@ -1,5 +1,6 @@
 """MI355X-native (gfx950) CNN backbone + temporal Transformer encoder hot path."""
 from .modules import (ConvBNReLUPool, HybridCrossEntropyLoss, MultiheadAttention, TransformerCNNHybrid,  # noqa: F401
                       TransformerEncoder)
+from .optim import HybridAdamW  # noqa: F401
 
-__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss"]
+__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW"]

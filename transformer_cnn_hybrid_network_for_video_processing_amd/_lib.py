@@ -15,6 +15,7 @@ HYB_F32, HYB_BF16 = 0, 1
 _CTYPES = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
     "long long": ctypes.c_longlong,
     "unsigned long long": ctypes.c_ulonglong,
     "size_t": ctypes.c_size_t,
