@@ -73,9 +73,18 @@ class GradAllReducer:
         b = self.buckets[self._bucket_of[p]]
         b["pending"] -= 1
         if b["pending"] == 0:
-            grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in b["params"]]
-            torch._foreach_copy_(b["views"], grads)
+            self._fill(b)
             b["work"] = self._launch(b)
+
+    def _fill(self, b):
+        dst, src = [], []
+        for q, v in zip(b["params"], b["views"]):
+            if q.grad is None:
+                v.zero_()
+            elif q.grad.data_ptr() != v.data_ptr():          # (a gradient that already lives in its view needs no copy)
+                dst.append(v); src.append(q.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _launch(self, b):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -88,18 +97,18 @@ class GradAllReducer:
             if b["work"] is None:
                 if b["pending"] != len(b["params"]):
                     # some gradients of this bucket never arrived (unused parameters): reduce what is there
-                    grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in b["params"]]
-                    torch._foreach_copy_(b["views"], grads)
+                    self._fill(b)
                     b["work"] = self._launch(b)
                 else:
                     continue
             b["work"].wait()
             if not self._avg:
                 b["flat"].mul_(inv)
+            # hand the averaged gradients over WITHOUT a copy: p.grad becomes the bucket view.  The next step's zero_grad
+            # (set_to_none, the default) drops the views before the bucket is refilled; if the caller accumulates instead, autograd
+            # adds into the view in place and the refill copies it onto itself.
             for q, v in zip(b["params"], b["views"]):
-                if q.grad is None:
-                    q.grad = v.clone()
-            torch._foreach_copy_([q.grad for q in b["params"]], b["views"])
+                q.grad = v
             b["work"] = None
             b["pending"] = len(b["params"])
 
