@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restric
     }
 }
 
-template <typename T>
+// ROWS = false: dgamma/dbeta += block sums (float atomics; the public per-op entry point).  ROWS = true (encoder composite): the
+// block writes its sums as one partial row dgamma[blockIdx][2][D] (fixed order inside the block), summed later in a fixed order.
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip,
                                                               int accumulate_dskip, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -117,8 +119,24 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
             }
         }
     }
+    extern __shared__ float lnred[];
+    if (ROWS) {
+        // per-wave slots [4][2][D] (single owner per entry), then the four waves in a fixed order
+        float* mine = lnred + (threadIdx.x >> 6) * 2 * D;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { mine[ch * 8 + j] = dg[c][j]; mine[D + ch * 8 + j] = db[c][j]; }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * D; i += blockDim.x)
+            dgamma[(long long)blockIdx.x * 2 * D + i] = (lnred[i] + lnred[2 * D + i]) + (lnred[4 * D + i] + lnred[6 * D + i]);
+        return;
+    }
     // combine the block's 4 waves in LDS, then one atomic per feature per block
-    extern __shared__ float lnred[];          // [2][D]
     for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lnred[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -137,6 +155,14 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
         atomicAdd(dgamma + i, lnred[i]);
         atomicAdd(dbeta + i, lnred[D + i]);
     }
+}
+
+// [G rows][2][D] partial rows -> dgamma[D], dbeta[D] (overwritten), fixed order
+__global__ __launch_bounds__(1024) void ln_rows_reduce_kernel(const float* __restrict__ part, int G, int D, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    long long i; float v;
+    if (!rows_reduce_1024(part, G, 2LL * D, i, v)) return;
+    if (i < D) dgamma[i] = v; else dbeta[i - D] = v;
 }
 
 // mean over the S tokens of feature d of clip b: the loads are issued eight at a time (independent), the additions keep the
@@ -278,10 +304,33 @@ extern "C" int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, con
     if (blocks > 32) blocks = 32;
     const size_t lnlds = 2 * (size_t)D * sizeof(float);
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL(ln_residual_bwd_kernel<float>, dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, false>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL(ln_residual_bwd_kernel<bf16>, dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, false>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
     else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal (encoder composite): deterministic variant.  Writes hyb_ln_bwd_rows(M) partial rows [rows][2][D] to `part`;
+// hyb_ln_rows_reduce sums any number of such rows into dgamma/dbeta (overwriting them).
+int hyb_ln_bwd_rows(int M) { int b = hyb_cdiv(M, 4); return b > 32 ? 32 : b; }
+int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
+                             int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed,
+                             hipStream_t st) {
+    HYB_CHECK_ARG(dy && x && gamma && stats && dx && dskip && part && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC);
+    const int blocks = hyb_ln_bwd_rows(M);
+    const size_t lnlds = 8 * (size_t)D * sizeof(float);
+    if (dtype == HYB_F32)
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, true>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed);
+    else if (dtype == HYB_BF16)
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, true>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(ln_rows_reduce_kernel, dim3(hyb_cdiv(2 * D, 32)), dim3(1024), 0, st, part, rows, D, dgamma, dbeta);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -9,6 +9,11 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
                         const int* ldt, hipStream_t st);
+int hyb_ln_bwd_rows(int M);
+int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
+                             int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed,
+                             hipStream_t st);
+int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
@@ -175,7 +180,7 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const size_t M = (size_t)B * S;
     const size_t big = (size_t)(Hid > D ? Hid : D);
-    return 8 * align256(M * D * es) + 2 * align256(M * big * es);
+    return 8 * align256(M * D * es) + 2 * align256(M * big * es) + align256((size_t)2 * 32 * 2 * D * sizeof(float));      // + LayerNorm partial rows
 }
 
 extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
@@ -245,6 +250,8 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
     const size_t big = align256((size_t)M * (Hid > D ? Hid : D) * es);
     void* dh = ws + 8 * md;             // d(hmid)
     void* g1b = ws + 8 * md + big;      // d(LN1 input): its own buffer so that all six dW inputs of a layer are alive at its end
+    float* lnpart = (float*)(ws + 8 * md + 2 * big);     // LayerNorm affine-gradient partial rows of the layer's two calls
+    const int lnrows = hyb_ln_bwd_rows(M);
 
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
@@ -252,11 +259,9 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         const float* const* P = params + (size_t)i * 14;
         float* const* G = grads + (size_t)i * 14;
         void* gx = (i == 0) ? dx : gin[i & 1];
-        HYB_HIP_TRY(hipMemsetAsync(G[12], 0, (size_t)D * 4, st));
-        HYB_HIP_TRY(hipMemsetAsync(G[13], 0, (size_t)D * 4, st));
         // LN2 + residual + sqrt(.5) + dropout
-        HYB_TRY(hyb_ln_residual_bwd(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, G[12], G[13], M, D,
-                                    (float)sqrt(0.5), layer_p, drop_seed(seed, i), stream));
+        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, lnpart, M, D,
+                                         (float)sqrt(0.5), layer_p, drop_seed(seed, i), st));
         // FFN second Linear: dX = g1 . W2 (pre-transposed copy), dW/db in one launch
         { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {dh};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
@@ -264,8 +269,10 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         { const void* A_[1] = {dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
         // LN1 + residual
-        HYB_TRY(hyb_ln_residual_bwd(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1b, gx, 0, G[12], G[13], M, D, 1.0f, 0.f,
-                                    0ull, stream));
+        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1b, gx, 0,
+                                         lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, st));
+        // the layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients, fixed order
+        HYB_TRY(hyb_ln_rows_reduce(lnpart, 2 * lnrows, D, G[12], G[13], st));
         // output projection
         { const void* A_[1] = {g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
