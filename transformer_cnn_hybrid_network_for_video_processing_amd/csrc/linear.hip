@@ -340,6 +340,48 @@ __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
     }
 }
 
+// Same conversion on 64x64 tiles with 16-byte loads and 4-element stores in both orientations (N, K, ldt multiples of 4)
+template <typename T>
+__global__ __launch_bounds__(256) void convert_weights_vec_kernel(ConvertArgs a) {
+    __shared__ float tile[64][65];
+    const int g = blockIdx.z;
+    const int N = a.N[g], K = a.K[g];
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    if (n0 >= N || k0 >= K) return;
+    const float* W = a.W[g];
+    T* Wc = (T*)a.Wc[g];
+    T* Wt = (T*)a.Wt[g];
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i, n = n0 + r, k = k0 + c4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < N && k < K) {                                   // K % 4 == 0: the whole quad is inside
+            v = *reinterpret_cast<const f32x4*>(W + (long long)n * K + k);
+            T o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(v[j]);
+            if (sizeof(T) == 2) *reinterpret_cast<unsigned long long*>(Wc + (long long)n * K + k) = *reinterpret_cast<const unsigned long long*>(o);
+            else *reinterpret_cast<f32x4*>(Wc + (long long)n * K + k) = *reinterpret_cast<const f32x4*>(o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[r][c4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i, k = k0 + r, n = n0 + c4;      // row r of the transposed tile = column r of the source tile
+        if (k < K && n < N) {
+            T o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(tile[c4 + j][r]);
+            T* dst = Wt + (long long)k * a.ldt[g] + n;
+            if (sizeof(T) == 2) *reinterpret_cast<unsigned long long*>(dst) = *reinterpret_cast<const unsigned long long*>(o);
+            else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(o);
+        }
+    }
+}
+
 // dym = dy * (y > 0)
 template <typename T>
 __global__ void relu_mask_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, long long n8) {
@@ -495,6 +537,18 @@ int hyb_convert_weights(int dtype, int count, const float* const* W, void* const
         if (K[i] > maxK) maxK = K[i];
     }
     dim3 grid(hyb_cdiv(maxK, 32), hyb_cdiv(maxN, 32), count);
+    bool vec = true;
+    for (int i = 0; i < count; ++i)
+        vec = vec && N[i] % 4 == 0 && K[i] % 4 == 0 && a.ldt[i] % 4 == 0 && ((uintptr_t)W[i] % 16 == 0) && ((uintptr_t)Wc[i] % 16 == 0) &&
+              ((uintptr_t)Wt[i] % 16 == 0);
+    if (vec) {
+        dim3 gridv(hyb_cdiv(maxK, 64), hyb_cdiv(maxN, 64), count);
+        if (dtype == HYB_F32) hipLaunchKernelGGL(convert_weights_vec_kernel<float>, gridv, dim3(256), 0, st, a);
+        else if (dtype == HYB_BF16) hipLaunchKernelGGL(convert_weights_vec_kernel<bf16>, gridv, dim3(256), 0, st, a);
+        else return HYB_E_ARG;
+        HYB_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == HYB_F32) hipLaunchKernelGGL(convert_weights_kernel<float>, grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(convert_weights_kernel<bf16>, grid, dim3(256), 0, st, a);
     else return HYB_E_ARG;
