@@ -11,6 +11,7 @@
 // A workgroup walks 8x32-pixel tiles.  The fp32 halo (10x34 pixels, prefetched one tile ahead into registers) is converted
 // to T and expanded into an im2col matrix P[pixel][k = tap*4 + c] in LDS; P rows feed the conv MFMA (k contiguous) and
 // P columns feed the wgrad MFMA through transposed LDS reads, so no scalar gathers are needed.
+#include <stdlib.h>
 #include "hyb_common.h"
 
 namespace {
@@ -530,7 +531,12 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
                              scale_shift, mean_invstd, (void*)st);
     }
     if (rc) return rc;
-    return s1_dispatch<T, 1>(a, gx, st);
+    // the apply+pool pass keeps no partial rows, so its grid is free: 2048 workgroups (shorter tile runs, 166 VGPRs = 3 workgroups
+    // per CU resident) measured +1 % of the step over 1024.  HYB_S1_APPLY_WGS overrides (A/B).
+    static const int apply_wgs = getenv("HYB_S1_APPLY_WGS") ? atoi(getenv("HYB_S1_APPLY_WGS")) : 2048;
+    int gx1 = apply_wgs > 0 ? apply_wgs : gx;
+    if (gx1 > numTiles) gx1 = (int)numTiles;
+    return s1_dispatch<T, 1>(a, gx1, st);
 }
 
 template <typename T>
