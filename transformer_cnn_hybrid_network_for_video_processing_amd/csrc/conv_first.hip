@@ -495,7 +495,8 @@ size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
 }
 
 static int s1_grid(long long numTiles) {
-    long long g = numTiles < S1_MAXPART ? numTiles : S1_MAXPART;
+    static const int fwd_wgs = getenv("HYB_S1_FWD_WGS") ? atoi(getenv("HYB_S1_FWD_WGS")) : S1_MAXPART;         // <= S1_MAXPART (workspace)
+    long long g = numTiles < fwd_wgs ? numTiles : fwd_wgs;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -565,7 +566,8 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
     // one pass over x and dpooled (MODE 4), a fixed-order sum of the partial rows, and a finalize on tiny matrices
-    int gx = (int)(numTiles < S1_BWD_PART ? numTiles : S1_BWD_PART);
+    static const int bwd_wgs = getenv("HYB_S1_BWD_WGS") ? atoi(getenv("HYB_S1_BWD_WGS")) : S1_BWD_PART;      // <= S1_BWD_PART (workspace)
+    int gx = (int)(numTiles < bwd_wgs ? numTiles : bwd_wgs);
     if (gx < 1) gx = 1;
     const long long roww = (long long)Cop * 48 + 2304;
     int rc = s1_dispatch<T, 4>(a, gx, st);
