@@ -88,7 +88,7 @@ def conv_kernel_table(args, dt_code, tdt, dev):
             def s1f():
                 lib.call("hyb_convstage_fwd", dt_code, 1, x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                          nbt.data_ptr(), 1, 0.1, 1e-5, N, H, H, ci, 0, co, co, None, pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(),
-                         None, wsf.data_ptr(), wsf.numel(), st)
+                         None, None, wsf.data_ptr(), wsf.numel(), st)
 
             def s1b():
                 lib.call("hyb_convstage_bwd", dt_code, 1, dp.data_ptr(), x.data_ptr(), None, w.data_ptr(), gamma.data_ptr(), ss.data_ptr(), mi.data_ptr(),

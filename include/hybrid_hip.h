@@ -11,9 +11,14 @@
  * Contract:
  *   - extern "C", plain pointers and sizes only; no torch types.
  *   - the CALLER owns every buffer (inputs, outputs, saved activations, workspace);
- *     the library never allocates or frees device memory and keeps no global state.
+ *     the library never allocates or frees device memory.  Process-global state is limited to
+ *     (i) the optional measurement hooks of hyb_profile_set (off unless set; measurement runs only),
+ *     (ii) per-kernel "dynamic-LDS attribute already set on device d" bitmasks (lock-free, idempotent) and
+ *     (iii) the HYB_* debug switches, each read from the environment once.
+ *     None of it depends on the data or changes results.
  *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and
- *     returns immediately; no internal synchronisation; re-entrant.
+ *     returns immediately; no internal synchronisation; re-entrant (concurrent calls from several host threads
+ *     and on several devices are allowed).
  *   - return value: 0 = success; negative = argument check failed (HYB_E_*);
  *     positive = hipError_t from a launch.  Nothing throws across the ABI.
  *   - `dtype` selects the storage/MFMA-operand type T of activations:
@@ -51,10 +56,12 @@ int hyb_pad_channels(int c);
 /* ---- measurement hook (bench.py): time ONE kernel launch inside a real step with HIP events -----------
  * hyb_profile_set(slot, kernel_id, a, b, ev_start, ev_stop): the next launches of kernel `kernel_id` whose shape key is
  * (a, b) record hipEvent_t ev_start / ev_stop on the launch stream immediately before / after that kernel only.
- *   kernel_id 1: conv3x3_nhwc_kernel        (a = Cip, b = Cop as passed to hyb_conv3x3_fwd; forward and dgrad launches)
- *   kernel_id 2: conv3x3_wgrad_kernel       (a = Cip, b = Cop)
- * slot in [0, 16).  hyb_profile_clear() removes all hooks.  This is the only process-global state in the library; it is
- * never touched unless a hook is set, and it is not thread-safe (measurement runs only). */
+ *   kernel_id 1: the conv contraction kernel of hyb_conv3x3_fwd -- conv3x3_v2_kernel (bf16, shapes with an asynchronous
+ *                variant) or the first-generation conv3x3_nhwc_kernel -- (a = Cip, b = Cop as passed; forward and dgrad launches)
+ *   kernel_id 2: the weight-gradient contraction kernel -- wgrad_v2_kernel or the first-generation conv3x3_wgrad_kernel --
+ *                (a = Cip, b = Cop)
+ * slot in [0, 16).  hyb_profile_clear() removes all hooks.  The hook table is never touched unless a hook is set, and it is
+ * not thread-safe (measurement runs only). */
 int hyb_profile_set(int slot, int kernel_id, int a, int b, void* ev_start, void* ev_stop);
 int hyb_profile_clear(void);
 
@@ -99,13 +106,16 @@ int hyb_conv3x3_fwd(int dtype, int first, const void* x, const void* wp, void* y
 int hyb_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, long long* num_batches_tracked, int training, float momentum,
                     float eps, long long count, int Co, int Cop, float* scale_shift, float* mean_invstd,
+                    float* running_out /* NULL: update running_mean/var/num_batches_tracked in place (nn.BatchNorm2d semantics);
+                                          else fp32 [2][Co] receiving the UPDATED (mean, var) while the inputs stay untouched and
+                                          num_batches_tracked is left to the caller (functional form, for torch custom ops) */,
                     void* stream);
 
 /* training-mode shortcut: the same, computed straight from the G per-workgroup partial rows hyb_conv3x3_fwd left in
  * `stats_partials` (fixed-order sum + finalize in one launch).  G = hyb_conv_stats_rows(...). */
 int hyb_bn_stats_finalize(const float* stats_partials, int G, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, long long* num_batches_tracked, float momentum, float eps, long long count,
-                          int Co, int Cop, float* scale_shift, float* mean_invstd, void* stream);
+                          int Co, int Cop, float* scale_shift, float* mean_invstd, float* running_out /* as above */, void* stream);
 
 /* pooled[N,H/2,W/2,Cop] = maxpool2x2(relu(y*scale+shift)) (floor; H,W >= 2) */
 int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, void* pooled,
@@ -144,6 +154,7 @@ int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, 
                       void* y_raw /* [N,H,W,Cop] T, saved */, void* pooled /* [N,H/2,W/2,Cop] T */,
                       float* scale_shift /* [2][Cop] saved */, float* mean_invstd /* [2][Cop] saved */,
                       void* packed_bwd /* NULL, or hyb_convstage_packed_bwd_elems() T elements: weights packed for backward, saved */,
+                      float* running_out /* NULL = in-place running statistics; else [2][Co], see hyb_bn_finalize (training only) */,
                       void* workspace, size_t workspace_bytes, void* stream);
 long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop);
 size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop);
@@ -219,7 +230,9 @@ int hyb_head_fwd(int dtype, const void* x /* [B,S,D] T */, const float* W /* [C,
 int hyb_head_bwd(int dtype, const void* x, const float* W, const float* dlogits /* [B,C] */,
                  void* dx /* [B,S,D] T */, float* dW, float* db, int B, int S, int D, int C, void* stream);
 
-/* ---- loss: mean cross-entropy over the batch (composite's own) ------------------------ */
+/* ---- loss: mean cross-entropy over the batch (composite's own) ------------------------
+ * A target outside [0, C) (torch raises a device-side assert there) makes the loss and that row of dlogits NaN; nothing is
+ * read out of bounds. */
 int hyb_cross_entropy_fwd(const float* logits, const long long* target, float* loss /* [1] */,
                           int B, int C, void* stream);
 int hyb_cross_entropy_bwd(const float* logits, const long long* target, const float* dloss /* [1] */,

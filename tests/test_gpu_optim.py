@@ -54,3 +54,36 @@ def test_adamw_on_the_model_and_state_dict_round_trip():
     o3 = P.HybridAdamW(m2.parameters(), lr=1e-3)
     o3.load_state_dict(sd)
     assert int(o3.state[next(iter(m2.parameters()))]["step"]) == 2
+
+
+def test_adamw_reload_into_the_same_optimizer_midrun():
+    """load_state_dict after a step replaces the moment tensors; the cached device-pointer tables must follow
+    (they used to keep pointing at the old, freed moments).  step, save, step, roll back, step == torch doing the same."""
+    import copy
+    init = _params(3)
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    b = [torch.nn.Parameter(t.clone()) for t in init]
+    oa, ob = torch.optim.AdamW(a, lr=1e-3), P.HybridAdamW(b, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+
+    def grads():
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad = gr.clone(); pb.grad = gr.clone()
+    grads(); oa.step(); ob.step()
+    sa, sb = copy.deepcopy(oa.state_dict()), copy.deepcopy(ob.state_dict())
+    wa, wb = [p.detach().clone() for p in a], [p.detach().clone() for p in b]
+    grads(); oa.step(); ob.step()
+    oa.load_state_dict(sa); ob.load_state_dict(sb)                    # roll both back to after step 1
+    with torch.no_grad():
+        for p, w in zip(a, wa):
+            p.copy_(w)
+        for p, w in zip(b, wb):
+            p.copy_(w)
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]     # recycle freed blocks with poison
+    del junk
+    grads(); oa.step(); ob.step()
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pb.data, pa.data, rtol=2e-6, atol=2e-7)
+        torch.testing.assert_close(ob.state[pb]["exp_avg"], oa.state[pa]["exp_avg"], rtol=2e-6, atol=1e-12)
+        assert int(ob.state[pb]["step"]) == 2

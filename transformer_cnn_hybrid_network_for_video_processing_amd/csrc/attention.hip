@@ -287,7 +287,7 @@ int attn_fwd_t(const void* q, const void* k, const void* v, const float* mask, v
     const size_t lds = attn_fwd_lds<T>(d);
     if (lds > 160 * 1024) return HYB_E_ARG;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // size varies per call: not cached
         if (e != hipSuccess) return (int)e;
     }
     const float scale = 1.0f / sqrtf((float)d.D);

@@ -7,11 +7,11 @@ namespace {
 
 // ---- BN statistics -> scale/shift -------------------------------------------------------
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                   float* running_mean, float* running_var, long long* __restrict__ nbt,
                                    int training, float momentum, float eps, long long count, int Co, int Cop,
-                                   float* __restrict__ scale_shift, float* __restrict__ mean_invstd) {
+                                   float* __restrict__ scale_shift, float* __restrict__ mean_invstd, float* running_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && training && nbt) *nbt += 1;
+    if (c == 0 && training && nbt && !running_out) *nbt += 1;
     if (c >= Cop) return;
     float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
     if (c < Co) {
@@ -24,8 +24,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
             var = fmaxf(var, 0.f);
             invstd = rsqrtf(var + eps);
             const float unbiased = count > 1 ? var * ((float)count / (float)(count - 1)) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            // functional form (running_out != NULL): the updated statistics go to running_out[2][Co], the inputs stay untouched
+            (running_out ? running_out : running_mean)[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            (running_out ? running_out + Co : running_var)[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
         } else {
             mean = running_mean[c];
             invstd = rsqrtf(running_var[c] + eps);
@@ -40,14 +41,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
 
 // partial rows [G][2][Cop] -> statistics -> finalize, one launch (1024 threads: 32 channels x 32 row groups per block)
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int G, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                                 float* __restrict__ running_var, long long* __restrict__ nbt, float momentum,
+                                                                 const float* __restrict__ beta, float* running_mean,
+                                                                 float* running_var, long long* __restrict__ nbt, float momentum,
                                                                  float eps, long long count, int Co, int Cop, float* __restrict__ scale_shift,
-                                                                 float* __restrict__ mean_invstd) {
+                                                                 float* __restrict__ mean_invstd, float* running_out) {
     long long i1, i2; float s1 = 0.f, s2 = 0.f;
     const bool ok1 = rows_reduce_1024(part, G, 2ll * Cop, i1, s1, 0, Cop);
     const bool ok2 = rows_reduce_1024(part, G, 2ll * Cop, i2, s2, Cop, Cop);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && !running_out) *nbt += 1;
     if (!(ok1 && ok2)) return;
     const int c = (int)i1;
     float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __
         float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
         invstd = rsqrtf(var + eps);
         const float unbiased = count > 1 ? var * ((float)count / (float)(count - 1)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        (running_out ? running_out : running_mean)[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        (running_out ? running_out + Co : running_var)[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
     const float scale = g * invstd;
     scale_shift[c] = scale;
@@ -369,17 +370,17 @@ extern "C" int hyb_profile_clear(void) {
     return 0;
 }
 
-extern "C" int hyb_abi_version(void) { return 1; }
+extern "C" int hyb_abi_version(void) { return 2; }
 extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
 extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }
 
 extern "C" int hyb_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                long long* nbt, int training, float momentum, float eps, long long count, int Co, int Cop,
-                               float* scale_shift, float* mean_invstd, void* stream) {
+                               float* scale_shift, float* mean_invstd, float* running_out, void* stream) {
     HYB_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && mean_invstd && Co > 0 && Cop >= Co && count > 0);
     HYB_CHECK_ARG(!training || stats);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(hyb_cdiv(Cop, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, running_mean,
-                       running_var, nbt, training, momentum, eps, count, Co, Cop, scale_shift, mean_invstd);
+                       running_var, nbt, training, momentum, eps, count, Co, Cop, scale_shift, mean_invstd, running_out);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -400,10 +401,10 @@ extern "C" size_t hyb_bn_bwd_reduce_workspace(int Cop) { return Cop > 0 ? (size_
 
 extern "C" int hyb_bn_stats_finalize(const float* stats_partials, int G, const float* gamma, const float* beta, float* running_mean,
                                      float* running_var, long long* nbt, float momentum, float eps, long long count, int Co, int Cop,
-                                     float* scale_shift, float* mean_invstd, void* stream) {
+                                     float* scale_shift, float* mean_invstd, float* running_out, void* stream) {
     HYB_CHECK_ARG(stats_partials && G > 0 && gamma && beta && running_mean && running_var && scale_shift && mean_invstd && Co > 0 && Cop >= Co && count > 0);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(hyb_cdiv(Cop, 32)), dim3(1024), 0, (hipStream_t)stream, stats_partials, G, gamma, beta,
-                       running_mean, running_var, nbt, momentum, eps, count, Co, Cop, scale_shift, mean_invstd);
+                       running_mean, running_var, nbt, momentum, eps, count, Co, Cop, scale_shift, mean_invstd, running_out);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -465,8 +465,8 @@ template <typename T, int NT, int MODE>
 int s1_launch(S1Args a, int grid_x, hipStream_t st) {
     const size_t lds = s1_lds_bytes<T, NT, MODE>();
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)stage1_kernel<T, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static HybAttrOnce once;                               // per template instantiation (lds is a compile-time size), per device
+        if (int e = hyb_set_lds_attr(once, (const void*)stage1_kernel<T, NT, MODE>, (int)lds)) return e;
     }
     dim3 grid(grid_x, a.Cop / (NT * 16));
     hipLaunchKernelGGL((stage1_kernel<T, NT, MODE>), grid, dim3(256), lds, st, a);
@@ -503,7 +503,8 @@ static int s1_grid(long long numTiles) {
 template <typename T>
 static int stage1_fwd_t(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co,
-                        int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st) {
+                        int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out,
+                        hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = packed_out ? (T*)packed_out : (T*)ws; ws += al256((size_t)Cop * 64 * es);      // packed weights are kept for backward when asked
@@ -526,10 +527,10 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
         rc = s1_dispatch<T, 0>(a, gx, st);
         if (rc) return rc;
         rc = hyb_bn_stats_finalize(part, gx, gamma, beta, running_mean, running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop,
-                                   scale_shift, mean_invstd, (void*)st);
+                                   scale_shift, mean_invstd, running_out, (void*)st);
     } else {
         rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, 0, momentum, eps, (long long)N * H * W, Co, Cop,
-                             scale_shift, mean_invstd, (void*)st);
+                             scale_shift, mean_invstd, nullptr, (void*)st);
     }
     if (rc) return rc;
     // the apply+pool pass keeps no partial rows, so its grid is free: 2048 workgroups (shorter tile runs, 166 VGPRs = 3 workgroups
@@ -582,10 +583,10 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
 
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st) {
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, st);
-    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, st);
+    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, st);
+    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, st);
     return HYB_E_ARG;
 }
 

@@ -456,9 +456,9 @@ int launch_conv_ck(const T* x, const T* wp, T* y, float* stats, float* part, int
     if (gx < 1) gx = 1;
     dim3 grid(gx, gy);
     if (lds > 64 * 1024) {
-        const void* f = part ? (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true, WLDS> : (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false, WLDS>;
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        static HybAttrOnce once_stats, once_plain;             // per template instantiation (lds is fixed by it), per device
+        if (int e = part ? hyb_set_lds_attr(once_stats, (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, true, WLDS>, (int)lds)
+                         : hyb_set_lds_attr(once_plain, (const void*)conv3x3_nhwc_kernel<T, NT, CB, PG, CK, false, WLDS>, (int)lds)) return e;
     }
     HybProfileHook* hook = hyb_find_hook(1, Cip, Cop);
     if (hook) hipEventRecord(hook->ev0, st);

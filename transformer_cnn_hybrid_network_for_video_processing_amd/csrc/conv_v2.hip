@@ -360,14 +360,9 @@ int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H,
     if (gx < 1) gx = 1;
     gx = hyb_cdiv(numTiles, hyb_cdiv(numTiles, gx));          // contiguous runs of ceil(numTiles / gx) tiles: drop the empty ones
     const dim3 grid(gx, Cop / G::CBW);
-    static bool attr_set = false;                              // per template instantiation: the attribute sticks to the function
-    if (!attr_set) {
-        for (const void* fn : {(const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>, (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>}) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr_set = true;
-    }
+    static HybAttrOnce once_stats, once_plain;                 // per template instantiation, per device
+    if (int e = hyb_set_lds_attr(once_stats, (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>, (int)G::LDS_BYTES)) return e;
+    if (int e = hyb_set_lds_attr(once_plain, (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>, (int)G::LDS_BYTES)) return e;
     if (part)
         hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>), grid, dim3(G::NW * 64), G::LDS_BYTES, st, x, wp, y, part, N, H, W, Cip, Cop,
                            tilesX, tilesY, (int)numTiles, stat_rows);

@@ -611,12 +611,8 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
 template <bool FUSE, int CI, int CW, int PW>
 int w2_launch_cw(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, const bf16* dy, float* slab, int N, int H, int W, int Cip, int Cop,
                  int tX, int tY, int nT, const WgradFuse& fz) {
-    static bool attr_set = false;                              // per template instantiation: the attribute sticks to the function
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_v2_kernel<FUSE, CI, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2X<CI>::LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static HybAttrOnce once;                                   // per template instantiation, per device
+    if (int e = hyb_set_lds_attr(once, (const void*)wgrad_v2_kernel<FUSE, CI, CW, PW>, (int)W2X<CI>::LDS)) return e;
     if (hook) hipEventRecord(hook->ev0, st);
     hipLaunchKernelGGL((wgrad_v2_kernel<FUSE, CI, CW, PW>), grid, dim3((CW + PW) * 64), W2X<CI>::LDS, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
     if (hook) hipEventRecord(hook->ev1, st);

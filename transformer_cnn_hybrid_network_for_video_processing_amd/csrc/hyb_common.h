@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "hybrid_hip.h"
 
 typedef __bf16 bf16;
@@ -17,6 +18,21 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define HYB_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static inline int hyb_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) sticks to (function, device).  One HybAttrOnce per kernel instantiation
+// remembers the devices it has been set on in a lock-free bitmask: the call is idempotent, so two threads racing on the
+// first launch merely both make it; a second device in the same process gets its own call.
+struct HybAttrOnce { std::atomic<unsigned long long> done{0}; };
+static inline int hyb_set_lds_attr(HybAttrOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.done.load(std::memory_order_acquire) & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    once.done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 // measurement hooks (hyb_profile_set): defined in bn_pool.hip
 struct HybProfileHook { int kernel_id, a, b; hipEvent_t ev0, ev1; };

@@ -256,7 +256,8 @@ __global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long*
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
         const long long t = target[b];
-        acc += (logf(s) + mx) - logits[b * C + (int)t];
+        // an out-of-range class index (torch raises a device assert) poisons the loss instead of reading out of bounds
+        acc += (t >= 0 && t < C) ? (logf(s) + mx) - logits[b * C + (int)t] : NAN;
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -275,8 +276,9 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
     const float g = dloss[0] / (float)B;
-    const int t = (int)target[b];
-    for (int c = 0; c < C; ++c) dlogits[b * C + c] = g * (expf(logits[b * C + c] - mx) / s - (c == t ? 1.f : 0.f));
+    const long long t = target[b];
+    const bool ok = t >= 0 && t < C;                          // out of range: NaN gradient row (see ce_fwd_kernel)
+    for (int c = 0; c < C; ++c) dlogits[b * C + c] = ok ? g * (expf(logits[b * C + c] - mx) / s - (c == (int)t ? 1.f : 0.f)) : NAN;
 }
 
 }  // namespace

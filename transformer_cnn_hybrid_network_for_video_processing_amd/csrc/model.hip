@@ -29,7 +29,7 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop);
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop);
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, hipStream_t st);
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, hipStream_t st);
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
                    float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
@@ -95,14 +95,14 @@ extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int
 extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                                  int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
-                                 float* mean_invstd, void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(x && weight && gamma && beta && running_mean && running_var && (first || y_raw) && pooled && scale_shift && mean_invstd && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(H >= 2 && W >= 2 && Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0);
     if (workspace_bytes < hyb_convstage_fwd_workspace(dtype, first, Cip, Cop)) return HYB_E_WORKSPACE;
     if (first)      // stage 1: the raw conv output is never materialised (recomputed in backward), y_raw is ignored
         return hyb_stage1_fwd(dtype, (const float*)x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci,
-                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, (hipStream_t)stream);
+                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, running_out, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     void* wp = ws;
@@ -113,11 +113,11 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
     if (training) {   // conv leaves per-workgroup partial sums; one launch sums them in a fixed order and finalises BN
         HYB_TRY(hyb_conv3x3_fwd(dtype, 0, x, wp, y_raw, nullptr, part, N, H, W, Ci, Cip, Cop, stream));
         HYB_TRY(hyb_bn_stats_finalize(part, hyb_conv_stats_rows(0, N, H, W, Cop), gamma, beta, running_mean, running_var, nbt, momentum, eps,
-                                      (long long)N * H * W, Co, Cop, scale_shift, mean_invstd, stream));
+                                      (long long)N * H * W, Co, Cop, scale_shift, mean_invstd, running_out, stream));
     } else {
         HYB_TRY(hyb_conv3x3_fwd(dtype, 0, x, wp, y_raw, nullptr, nullptr, N, H, W, Ci, Cip, Cop, stream));
         HYB_TRY(hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, 0, momentum, eps, (long long)N * H * W, Co, Cop,
-                                scale_shift, mean_invstd, stream));
+                                scale_shift, mean_invstd, nullptr, stream));
     }
     HYB_TRY(hyb_bn_relu_pool_fwd(dtype, y_raw, scale_shift, pooled, N, H, W, Cop, stream));
     return 0;

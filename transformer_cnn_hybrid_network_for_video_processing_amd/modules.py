@@ -10,7 +10,8 @@ keys follow the reference:
   reference harnesses call their models (Model.py:27,56 / FCT.py:302,330).
 
 Parameters are ordinary fp32 ``nn.Parameter``s, so stock AdamW, checkpointing and gradient
-all-reduce work unchanged.  All compute runs in the HIP library; CPU tensors raise RuntimeError.
+all-reduce work unchanged.  All compute runs in the HIP library through the ``torch.ops.hybrid.*`` custom operators
+(ops.py); CPU tensors raise RuntimeError.
 """
 import math
 from collections import OrderedDict
@@ -48,14 +49,14 @@ class ConvBNReLUPool(nn.Sequential, _ComputeDtypeMixin):
         self.in_channels, self.features = in_channels, features
         self._dt = ops.dtype_code(compute_dtype)
 
-    def forward_nhwc(self, x, first):
-        """x: NCHW fp32 frames when ``first`` else NHWC compute-dtype activations. Returns NHWC."""
+    def forward_nhwc(self, x, first, commit=None):
+        """x: NCHW fp32 frames when ``first`` else NHWC compute-dtype activations. Returns NHWC.  ``commit``: see ops.convstage."""
         conv, bn = getattr(self, self._conv), getattr(self, self._norm)
         if bn.momentum is None:
             raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
-        training = self.training or not bn.track_running_stats
-        return ops.ConvStageFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                     training, bn.momentum, bn.eps, self._dt, first)
+        training = self.training or not bn.track_running_stats or bn.running_mean is None
+        return ops.convstage(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                             training, bn.momentum, bn.eps, self._dt, first, commit)
 
     def forward(self, x):
         """Standalone use: [N,C,H,W] fp32 in, [N,features,H/2,W/2] fp32 out."""
@@ -92,9 +93,8 @@ class MultiheadAttention(nn.Module, _ComputeDtypeMixin):
     def forward(self, q, k, v, mask=None):                                           # src L67-89
         if self.input_dim % self.num_heads != 0:
             raise ValueError("input_dim must be divisible by num_heads")
-        cfg = (self._dt, self.num_heads, self._attn_p(), ops.next_seed())
-        out = ops.MultiheadAttentionFn.apply(ops.to_compute(q, self._dt), ops.to_compute(k, self._dt), ops.to_compute(v, self._dt),
-                                             mask, cfg, *self._params())
+        out = ops.mha(ops.to_compute(q, self._dt), ops.to_compute(k, self._dt), ops.to_compute(v, self._dt), mask, self._params(),
+                      self._dt, self.num_heads, self._attn_p(), ops.next_seed())
         return ops.to_f32(out, self._dt)
 
 
@@ -129,8 +129,8 @@ class TransformerEncoder(nn.Module, _ComputeDtypeMixin):
     def forward_compute(self, x, mask):
         """x already in the compute dtype ([B,S,D]); returns the compute dtype."""
         attn_p = self.attention_layers[0]._attn_p() if self.num_layers else 0.0
-        cfg = (self._dt, self.hidden_dim, self.num_layers, self.num_heads, attn_p, float(self.dropout), ops.next_seed())   # Q6: always active
-        return ops.EncoderFn.apply(x, mask, cfg, *self._flat_params())
+        return ops.encoder(x, mask, self._flat_params(), self._dt, self.hidden_dim, self.num_layers, self.num_heads, attn_p,
+                           float(self.dropout), ops.next_seed())                                  # Q6: the per-layer dropout is always active
 
     def forward(self, input, mask):                                                  # src L110-126
         return ops.to_f32(self.forward_compute(ops.to_compute(input, self._dt), mask), self._dt)
@@ -140,7 +140,7 @@ class HybridCrossEntropyLoss(nn.Module):
     """Mean cross-entropy over the batch (the composite's own loss), one HIP kernel each way."""
 
     def forward(self, logits, target):
-        return ops.CrossEntropyFn.apply(logits, target)
+        return ops.cross_entropy(logits, target)
 
 
 class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
@@ -172,12 +172,14 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
                                "(there is no CPU fallback)")
         B, T = x.shape[:2]
         f = x.reshape(B * T, *x.shape[2:]).float()                  # frames folded into the batch axis
+        commit = []                                                  # running-statistics write-back of all stages: one multi-tensor copy
         if self.in_channels <= 4:
-            h = self.encoder1.forward_nhwc(f, True)
+            h = self.encoder1.forward_nhwc(f, True, commit)
         else:
-            h = self.encoder1.forward_nhwc(ops.nchw_to_nhwc(f, self._dt, ops.pad_channels(self.in_channels)), False)
+            h = self.encoder1.forward_nhwc(ops.nchw_to_nhwc(f, self._dt, ops.pad_channels(self.in_channels)), False, commit)
         for i in range(1, self.num_stages):
-            h = getattr(self, f"encoder{i + 1}").forward_nhwc(h, False)
-        tok = ops.TokenFn.apply(h, self.token_proj.weight, self.token_proj.bias, self._dt).reshape(B, T, -1)
+            h = getattr(self, f"encoder{i + 1}").forward_nhwc(h, False, commit)
+        ops.commit_running_stats(commit)
+        tok = ops.token(h, self.token_proj.weight, self.token_proj.bias, self._dt).reshape(B, T, -1)
         enc = self.encoder.forward_compute(tok, mask)
-        return ops.HeadFn.apply(enc, self.head.weight, self.head.bias, self._dt)
+        return ops.head(enc, self.head.weight, self.head.bias, self._dt)

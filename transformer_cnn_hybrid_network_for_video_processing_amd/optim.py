@@ -18,6 +18,21 @@ class HybridAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached pointer tables of the tensors whose addresses never change
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables.clear()
+        for st in self.state.values():              # torch casts loaded state to the parameter's dtype/device; keep the layout the kernel needs
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k] = st[k].to(torch.float32).contiguous()
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = int(st["step"].item())
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_tables"):
+            self._tables.clear()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -40,12 +55,12 @@ class HybridAdamW(torch.optim.Optimizer):
             steps = {int(self.state[p]["step"]) for p in ps}
             if len(steps) != 1:
                 raise RuntimeError("HybridAdamW: parameters of one group must share the step count")
-            key = tuple(id(p) for p in ps)
+            # the cached pointer tables are valid only while every parameter AND both of its moment tensors stay where they are:
+            # load_state_dict() / a rollback replaces the moments with new allocations (the old ones may already be freed)
+            addrs = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps]
             tab = self._tables.get(gi)
-            if tab is None or tab[0] != key or any(p.data_ptr() != a for p, a in zip(ps, tab[1])):
-                addrs = [p.data_ptr() for p in ps]
-                tab = (key, addrs, ptr_array(addrs), ptr_array([self.state[p]["exp_avg"].data_ptr() for p in ps]),
-                       ptr_array([self.state[p]["exp_avg_sq"].data_ptr() for p in ps]),
+            if tab is None or tab[1] != addrs:
+                tab = (None, addrs, ptr_array([a[0] for a in addrs]), ptr_array([a[1] for a in addrs]), ptr_array([a[2] for a in addrs]),
                        (ctypes.c_longlong * len(ps))(*[p.numel() for p in ps]))
                 self._tables[gi] = tab
             grads = []
