@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: clips/sec of one full harness step on BASELINE config 2
+"""Benchmark of the hot path: clips/sec of one full harness step.  Default = BASELINE config 2
 ([B=8 per GPU, T=16, 3, 224, 224], 4-stage CNN 32-64-128-256 + 2-layer transformer d=512 h=8, bf16).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,4,5}] [--dtype {bf16,fp32}]
+
+`--gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF (a child `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` of this same file, before this process touches the GPU), forwards
+rank 0's JSON line and exits with the child's status.  Launched by torch.distributed.run directly (RANK/WORLD_SIZE set) it is
+one rank of that job.
 
 A step = zero_grad -> forward -> cross-entropy -> backward -> (RCCL gradient all-reduce when N>1) -> AdamW.step, i.e. the
 reference harness inner loop (Model.py:55-59 / FCT.py:328-338) with nothing skipped; synthetic clips are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line (see the task contract) including
 
+  "fwd_bwd_only": the same K steps without zero_grad/AdamW (the metric's literal "fwd+bwd"), timed right after the headline
   "roofline":     the dominant HIP kernel, timed live with events on the launch stream, against the MI355X peak
   "cpu_baseline": the CPU oracle (oracle/hybrid_ref.py, kind "port") timed on the host cores on a bounded sample
+
+Configs (BASELINE.json `configs`; config 2 is the one the metric is quoted on, the others are labelled in config.workload):
+  2  [8,16,3,224,224]  d=512 h=8 hid=2048      4  [8,64,3,224,224]  d=768 h=8 hid=3072      5  [4,16,3,448,448]  d=512 h=8 hid=2048
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,29 +35,81 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md, chip-leve
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # HBM3E spec peak (6.29 TB/s measured copy)
 
-CFG = dict(B=8, T=16, H=224, W=224, cnn_channels=(32, 64, 128, 256), d_model=512, num_heads=8, num_layers=2,
-           hidden_dim=2048, num_classes=8)
+CFG = dict(cnn_channels=(32, 64, 128, 256), num_layers=2, num_classes=8)
+CONFIGS = {
+    2: dict(batch=8, frames=16, size=224, d_model=512, num_heads=8, hidden_dim=2048),
+    4: dict(batch=8, frames=64, size=224, d_model=768, num_heads=8, hidden_dim=3072),
+    5: dict(batch=4, frames=16, size=448, d_model=512, num_heads=8, hidden_dim=2048),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=CFG["B"], help="clips per GPU")
-    ap.add_argument("--frames", type=int, default=CFG["T"])
-    ap.add_argument("--size", type=int, default=CFG["H"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (defaults of the flags below)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--d-model", type=int, default=None)
+    ap.add_argument("--heads", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
     ap.add_argument("--optimizer", default="hybrid", choices=["hybrid", "torch"],
                     help="AdamW implementation of the step: this repo's one-launch kernel (SURVEY 8f-2) or torch.optim.AdamW(fused=True)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-fwd-bwd-only", action="store_true")
+    args = ap.parse_args(argv)
+    c = CONFIGS[args.config]
+    for flag, key in (("batch", "batch"), ("frames", "frames"), ("size", "size"), ("d_model", "d_model"), ("heads", "num_heads"), ("hidden", "hidden_dim")):
+        if getattr(args, flag) is None:
+            setattr(args, flag, c[key])
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD job (never exec: this process may be watched by a
+    profiler that already initialised the GPU), stream its output through, and return its exit status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    n_json = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            n_json += 1
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc == 0 and n_json != 1:
+        sys.stderr.write(f"bench.py: expected exactly one JSON line from rank 0, saw {n_json}\n")
+        rc = 1
+    return rc
+
+
+torch = None        # imported by _import_torch(): the self-launching parent (`--gpus N`, no launcher) must stay clear of the GPU runtime
+
+
+def _import_torch():
+    global torch
+    if torch is None:
+        import torch as _torch
+        torch = _torch
+    return torch
 
 
 def conv_kernel_table(args, dt_code, tdt, dev):
     """Time the contraction kernels of one step standalone through the C ABI (HIP events on the launch stream = torch's
     current stream).  Rows with calls/step > 0 and composite=False are single kernels whose name appears in rocprof."""
+    _import_torch()
     from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib
     st = torch.cuda.current_stream().cuda_stream
     es = 2 if tdt == torch.bfloat16 else 4
@@ -135,6 +195,7 @@ def instep_kernel_table(args, step_fn, nsteps=8):
     """Time the nine conv contraction kernels INSIDE real training steps: the library records HIP events on the launch
     stream immediately around each hooked kernel (hyb_profile_set), one synchronised step at a time, outside the headline
     timed region so the headline is not perturbed."""
+    _import_torch()
     from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib
     N = args.batch * args.frames
     chans = (3,) + CFG["cnn_channels"]
@@ -199,12 +260,13 @@ def host_cores():
 
 def cpu_baseline(args):
     """The oracle (a port: stock torch fp32 on the host cores) on a bounded sample: 1 clip of the same shape."""
+    _import_torch()
     from oracle import hybrid_ref as R
     cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    m = R.TransformerCNNHybridRef(cnn_channels=CFG["cnn_channels"], d_model=CFG["d_model"], num_heads=CFG["num_heads"],
-                                  num_layers=CFG["num_layers"], hidden_dim=CFG["hidden_dim"], num_classes=CFG["num_classes"])
+    m = R.TransformerCNNHybridRef(cnn_channels=CFG["cnn_channels"], d_model=args.d_model, num_heads=args.heads,
+                                  num_layers=CFG["num_layers"], hidden_dim=args.hidden, num_classes=CFG["num_classes"])
     m.train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
     x, y = R.synthetic_batch(1, args.frames, args.size, args.size, CFG["num_classes"], seed=0)
@@ -229,14 +291,20 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))                       # before ANY torch / HIP call in this process
+    _import_torch()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the numbers would not be what the command line says")
+    single_dev = bool(os.environ.get("HYB_SINGLE_DEVICE"))        # test hook: several ranks share cuda:0 (one-GPU box, gloo backend)
+    if not single_dev and torch.cuda.device_count() < world:      # (device_count does not initialise the GPU runtime)
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    if os.environ.get("HYB_SINGLE_DEVICE"):       # test hook: several ranks share cuda:0 (one-GPU box, gloo backend)
+    if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -253,9 +321,9 @@ def main():
     from transformer_cnn_hybrid_network_for_video_processing_amd.dp import GradAllReducer
     from transformer_cnn_hybrid_network_for_video_processing_amd import ops
 
-    torch.manual_seed(0)                     # identical weights on every rank (also broadcast below)
-    model = P.TransformerCNNHybrid(cnn_channels=CFG["cnn_channels"], d_model=CFG["d_model"], num_heads=CFG["num_heads"],
-                                   num_layers=CFG["num_layers"], hidden_dim=CFG["hidden_dim"], num_classes=CFG["num_classes"],
+    torch.manual_seed(0)                     # identical weights on every rank (also broadcast below); dropout seeds differ per rank (ops.next_seed)
+    model = P.TransformerCNNHybrid(cnn_channels=CFG["cnn_channels"], d_model=args.d_model, num_heads=args.heads,
+                                   num_layers=CFG["num_layers"], hidden_dim=args.hidden, num_classes=CFG["num_classes"],
                                    dropout=0.0, compute_dtype=args.dtype).to(dev)
     model.train()
     crit = P.HybridCrossEntropyLoss()
@@ -281,27 +349,51 @@ def main():
         opt.step()
         return loss
 
+    def fwd_bwd():                              # the metric's literal "fwd+bwd": gradients (all-reduced when N>1), no optimizer
+        for p in params:
+            p.grad = None
+        loss = crit(model(x), y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finalize()
+        return loss
+    params = list(model.parameters())
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, loss = timed(step, args.steps)
     final_loss = float(loss.item())
+    fb = None
+    if not args.no_fwd_bwd_only:
+        fwd_bwd()
+        fdt, _ = timed(fwd_bwd, args.steps)
+        fb = {"value": args.batch * world * args.steps / fdt, "unit": "clips/s", "ms_per_step": fdt / args.steps * 1e3,
+              "step": "fwd+cross_entropy+bwd" + ("+grad_allreduce" if world > 1 else "") + " (no zero_grad, no optimizer); same K steps, timed after the headline"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
+        labels = {2: "config 2", 4: "config 4 (long clip)", 5: "config 5 (high-res)"}
+        is_cfg = all(getattr(args, k) == v for k, v in (("batch", CONFIGS[args.config]["batch"]), ("frames", CONFIGS[args.config]["frames"]),
+                                                        ("size", CONFIGS[args.config]["size"]), ("d_model", CONFIGS[args.config]["d_model"]),
+                                                        ("heads", CONFIGS[args.config]["num_heads"]), ("hidden", CONFIGS[args.config]["hidden_dim"])))
         out = {
             "metric": "clips/sec fwd+bwd, [B=8,T=16,3,224,224] d=512, 1/2/4/8 MI355X",
             "value": args.batch * world * args.steps / dt,
@@ -315,30 +407,34 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"config 2: clips [{args.batch},{args.frames},3,{args.size},{args.size}] per GPU, CNN 32-64-128-256 + "
-                                   f"2-layer transformer d=512 h=8 hid=2048, 8 classes",
+            "config": {"workload": f"{labels[args.config] if is_cfg else 'custom'}: clips [{args.batch},{args.frames},3,{args.size},{args.size}] per GPU, "
+                                   f"CNN 32-64-128-256 + 2-layer transformer d={args.d_model} h={args.heads} hid={args.hidden}, 8 classes",
                        "global_batch": args.batch * world, "frames": args.frames,
                        "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw",
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
-                       "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)"},
+                       "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",
+                       "logits_parity": "fp32 mode: <=1e-3 rel vs the CPU oracle (north_star gate); bf16 mode: ~5e-3 (reported, tests/test_gpu_fullsize.py)"},
             "final_loss": final_loss,
         }
+        if fb is not None:
+            out["fwd_bwd_only"] = fb
         if not args.no_roofline and world == 1:
-            dt_code = ops.dtype_code(args.dtype)
             rows = instep_kernel_table(args, step)
             dom = dominant_kernel(rows)
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")          # PMC bytes per launch (rocprofv3 --pmc)
-            if os.path.exists(tpath) and args.dtype == "bf16":
-                t = json.load(open(tpath)).get(dom["name"])
-                if t:
-                    traffic = t["hbm_bytes_per_launch"]
+            traffic, tsrc = None, None
+            for tname in ("r02_traffic.json", "r01_traffic.json"):           # PMC bytes per launch (rocprofv3 --pmc passes of this command)
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tpath) and args.dtype == "bf16" and args.config == 2 and is_cfg:
+                    t = json.load(open(tpath)).get(dom["name"])
+                    if t:
+                        traffic, tsrc = t["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                        break
             out["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "launches_per_step": dom["launches_per_step"],
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": traffic, "ms": dom["ms"], "flops_per_launch": dom["flops"],
+                               "traffic": traffic, "traffic_source": tsrc, "ms": dom["ms"], "flops_per_launch": dom["flops"],
                                "algorithmic_bytes_per_launch": dom["bytes"],
                                "how": "HIP events recorded by the library around this kernel inside 8 real steps (hyb_profile_set)"}
             out["kernel_table"] = [{"kernel": r["kernel"], "ms": round(r["ms"], 4), "TFLOPs": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),

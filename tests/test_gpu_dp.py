@@ -39,6 +39,27 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     assert d["final_loss"] == d["final_loss"]                                                  # finite
 
 
+def test_bench_plain_form_launches_its_own_ranks():
+    """VERDICT r1 / ADVICE r1: `python bench.py --gpus 2` (no launcher: the form the driver runs) must start 2 ranks itself
+    and report n_gpus == 2 -- it used to run one GPU silently."""
+    env = dict(os.environ, HYB_DIST_BACKEND="gloo", HYB_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--frames", "4",
+           "--size", "64", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["fwd_bwd_only"]["value"] > 0
+    # a launcher environment that disagrees with --gpus is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
+
+
 _RCCL_SNIPPET = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)

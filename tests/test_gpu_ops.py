@@ -1,0 +1,197 @@
+"""The drop-in boundary as custom torch operators (north_star: "exposed as custom torch ops"):
+torch.ops.hybrid.* exist, torch.library.opcheck accepts each of them (schema, fake/meta implementation, autograd
+registration, AOT dispatch) on small shapes, the modules route through them, and the argument checks the reference's torch
+code would have made are made here too (mask shape/device, class-index range, clip tensor that wants a gradient)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+OPCHECK_TESTS = ("test_schema", "test_autograd_registration", "test_faketensor", "test_aot_dispatch_static")
+
+
+def P():
+    import transformer_cnn_hybrid_network_for_video_processing_amd as pkg
+    return pkg
+
+
+def ops():
+    from transformer_cnn_hybrid_network_for_video_processing_amd import ops as o
+    return o
+
+
+def _opcheck(op, args, **kw):
+    torch.library.opcheck(op, args, test_utils=OPCHECK_TESTS, **kw)
+
+
+def test_namespace_holds_the_stage_operators():
+    ops()
+    for name in ("convstage", "convstage_bwd", "token", "token_bwd", "encoder", "encoder_bwd", "mha", "mha_bwd", "head", "head_bwd",
+                 "cross_entropy", "cross_entropy_bwd", "cast", "nchw_to_nhwc", "nhwc_to_nchw"):
+        assert hasattr(torch.ops.hybrid, name), name
+    s = str(torch.ops.hybrid.convstage.default._schema)
+    assert "(a!)" not in s and "running_mean" in s            # functional: running statistics are inputs, their update is an output
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("first,training", [(True, True), (False, True), (False, False)])
+def test_opcheck_convstage(dt, first, training):
+    o = ops()
+    tdt = o.torch_dtype(dt)
+    torch.manual_seed(0)
+    ci, co, N, H, W = (3, 32, 2, 8, 12) if first else (32, 64, 2, 8, 12)
+    x = torch.rand(N, ci, H, W, device="cuda") if first else torch.rand(N, H, W, ci, device="cuda").to(tdt).requires_grad_(True)
+    w = (torch.randn(co, ci, 3, 3, device="cuda") * 0.1).requires_grad_(True)
+    g = (torch.rand(co, device="cuda") + 0.5).requires_grad_(True)
+    b = torch.randn(co, device="cuda").requires_grad_(True)
+    rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+    _opcheck(torch.ops.hybrid.convstage.default, (x, w, g, b, rm, rv, training, 0.1, 1e-5, dt, first))
+    assert torch.equal(rm, torch.zeros_like(rm))                # the operator never touches its inputs
+    out = torch.ops.hybrid.convstage(x, w, g, b, rm, rv, training, 0.1, 1e-5, dt, first)
+    assert out[5].shape == ((2, co) if training else (0,))
+    dp = torch.randn_like(out[0])
+    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1], w.detach(), g.detach(), out[2], out[3], out[4], training, dt, first))
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
+def test_opcheck_token_head_ce(dt):
+    o = ops()
+    tdt = o.torch_dtype(dt)
+    torch.manual_seed(1)
+    x = torch.rand(6, 3, 3, 32, device="cuda").to(tdt).requires_grad_(True)
+    w = (torch.randn(16, 32, device="cuda") * 0.1).requires_grad_(True)
+    b = torch.randn(16, device="cuda").requires_grad_(True)
+    _opcheck(torch.ops.hybrid.token.default, (x, w, b, dt))
+    _opcheck(torch.ops.hybrid.token.default, (x, w, None, dt))
+    tok, feat = torch.ops.hybrid.token(x, w, b, dt)
+    _opcheck(torch.ops.hybrid.token_bwd.default, (torch.randn_like(tok), feat, w.detach(), 3, 3, True, dt))
+    e = tok.detach().reshape(2, 3, 16).requires_grad_(True)
+    hw = (torch.randn(5, 16, device="cuda") * 0.1).requires_grad_(True)
+    hb = torch.randn(5, device="cuda").requires_grad_(True)
+    _opcheck(torch.ops.hybrid.head.default, (e, hw, hb, dt))
+    _opcheck(torch.ops.hybrid.head_bwd.default, (torch.randn(2, 5, device="cuda"), e.detach(), hw.detach(), True, dt))
+    logits = torch.randn(4, 5, device="cuda", requires_grad=True)
+    y = torch.tensor([0, 4, 2, 2], device="cuda")
+    _opcheck(torch.ops.hybrid.cross_entropy.default, (logits, y))
+    _opcheck(torch.ops.hybrid.cross_entropy_bwd.default, (torch.ones((), device="cuda"), logits.detach(), y))
+    xf = torch.rand(2, 3, 4, 6, device="cuda", requires_grad=True)
+    _opcheck(torch.ops.hybrid.nchw_to_nhwc.default, (xf, dt, 32))
+    _opcheck(torch.ops.hybrid.nhwc_to_nchw.default, (torch.rand(2, 4, 6, 32, device="cuda").to(tdt).requires_grad_(True), dt, 3))
+    _opcheck(torch.ops.hybrid.cast.default, (xf, dt, True))
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_opcheck_encoder_and_mha(dt, use_mask):
+    o = ops()
+    tdt = o.torch_dtype(dt)
+    torch.manual_seed(2)
+    B, S, D, Hid, L, H = 2, 5, 32, 48, 2, 2
+    enc = P().TransformerEncoder(D, Hid, L, H, 0.1).cuda()
+    params = [p.detach().clone().requires_grad_(True) for p in enc._flat_params()]
+    x = torch.randn(B, S, D, device="cuda").to(tdt).requires_grad_(True)
+    mask = None
+    if use_mask:
+        mask = (torch.rand(B, S, S, device="cuda") > 0.3).float()
+        mask[:, :, 0] = 1
+    _opcheck(torch.ops.hybrid.encoder.default, (x, mask, params, dt, Hid, L, H, 0.1, 0.1, 1234))
+    out, saved = torch.ops.hybrid.encoder(x, mask, params, dt, Hid, L, H, 0.1, 0.1, 1234)
+    _opcheck(torch.ops.hybrid.encoder_bwd.default, (torch.randn_like(out), mask, [p.detach() for p in params], saved, dt, Hid, L, H, 0.1, 0.1, 1234))
+    mp = params[:8]
+    q, k, v = (torch.randn(B, S, D, device="cuda").to(tdt).requires_grad_(True) for _ in range(3))
+    _opcheck(torch.ops.hybrid.mha.default, (q, k, v, mask, mp, dt, H, 0.1, 99))
+    r = torch.ops.hybrid.mha(q, k, v, mask, mp, dt, H, 0.1, 99)
+    _opcheck(torch.ops.hybrid.mha_bwd.default, (torch.randn_like(r[0]), q.detach(), k.detach(), v.detach(), r[1], r[2], r[3], r[4], r[5],
+                                                [p.detach() for p in mp], dt, H, 0.1, 99))
+
+
+def test_modules_dispatch_through_the_operators():
+    """Every stage of the model's forward and backward is a torch.ops.hybrid.* call (seen by a dispatch mode)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    m = P().TransformerCNNHybrid(cnn_channels=(32, 64), d_model=32, num_heads=2, num_layers=1, hidden_dim=64).cuda()
+    x = torch.rand(2, 3, 3, 16, 16, device="cuda")
+    y = torch.tensor([1, 2], device="cuda")
+    with Spy():
+        loss = P().HybridCrossEntropyLoss()(m(x), y)
+        loss.backward()
+    hyb = [s for s in seen if s.startswith("hybrid.")]
+    for name in ("convstage", "token", "encoder", "head", "cross_entropy", "cross_entropy_bwd", "head_bwd", "encoder_bwd", "token_bwd", "convstage_bwd"):
+        assert any(s.startswith(f"hybrid.{name}.") for s in hyb), (name, hyb)
+    assert sum(s.startswith("hybrid.convstage.") for s in hyb) == 2 and sum(s.startswith("hybrid.convstage_bwd.") for s in hyb) == 2
+
+
+def test_mask_is_validated_like_the_reference_would():
+    """a CPU mask on a cuda model used to hand a host pointer to the kernel; [S,S] / wrong-B masks read out of bounds."""
+    enc = P().TransformerEncoder(32, 64, 1, 2, 0.0).cuda().eval()
+    mha = P().MultiheadAttention(32, 2).cuda().eval()
+    x = torch.randn(2, 6, 32, device="cuda")
+    for bad in (torch.ones(2, 6, 6), torch.ones(6, 6, device="cuda"), torch.ones(1, 6, 6, device="cuda"), torch.ones(3, 6, 6, device="cuda"),
+                torch.ones(2, 6, 5, device="cuda")):
+        with pytest.raises(RuntimeError, match="mask"):
+            enc(x, bad)
+        with pytest.raises(RuntimeError, match="mask"):
+            mha(x, x, x, bad)
+    # broadcastable along the query or key axis is what mask.repeat(H,1,1) + masked_fill accept too
+    keys = (torch.rand(2, 1, 6, device="cuda") > 0.3).float()
+    keys[:, :, 0] = 1
+    assert torch.equal(enc(x, keys), enc(x, keys.expand(2, 6, 6).contiguous()))
+    assert torch.equal(enc(x, keys.bool()), enc(x, keys))      # mask == 0 semantics for any dtype
+
+
+def test_cross_entropy_rejects_bad_targets():
+    crit = P().HybridCrossEntropyLoss()
+    logits = torch.randn(3, 4, device="cuda", requires_grad=True)
+    assert math.isnan(crit(logits, torch.tensor([0, 4, 1], device="cuda")).item())       # class index out of range: poisoned, not out-of-bounds
+    assert math.isnan(crit(logits, torch.tensor([0, -1, 1], device="cuda")).item())
+    with pytest.raises(ValueError):
+        crit(logits, torch.tensor([0, 1], device="cuda"))
+    good = crit(logits, torch.tensor([0, 3, 1], device="cuda"))
+    want = torch.nn.functional.cross_entropy(logits.detach().cpu(), torch.tensor([0, 3, 1]))
+    assert abs(good.item() - want.item()) < 1e-5
+
+
+def test_first_stage_input_gradient_is_refused_not_dropped():
+    stage = P().ConvBNReLUPool(3, 32, "enc1").cuda()
+    x = torch.rand(2, 3, 8, 8, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="does not compute a gradient for its input"):
+        stage(x)
+    m = P().TransformerCNNHybrid(cnn_channels=(32,), d_model=32, num_heads=2, num_layers=1, hidden_dim=32).cuda()
+    with pytest.raises(RuntimeError, match="does not compute a gradient for its input"):
+        m(torch.rand(1, 2, 3, 8, 8, device="cuda", requires_grad=True))
+    stage(x.detach()).sum().backward()                           # the normal case still works
+    assert stage.enc1conv1.weight.grad is not None
+
+
+def test_batchnorm_without_running_stats():
+    from oracle import hybrid_ref as R
+    torch.manual_seed(4)
+    ref = R.conv_stage(32, 32, "e")
+    ref.enorm1 = torch.nn.BatchNorm2d(32, track_running_stats=False)
+    hip = P().ConvBNReLUPool(32, 32, "e", compute_dtype="fp32")
+    hip.enorm1 = torch.nn.BatchNorm2d(32, track_running_stats=False)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda().eval()                                      # no running statistics: batch statistics even in eval mode
+    ref.eval()
+    x = torch.rand(2, 32, 8, 8)
+    got, want = hip(x.cuda()).cpu(), ref(x)
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+def test_dropout_seeds_differ_per_rank(monkeypatch):
+    o = ops()
+    torch.manual_seed(0)
+    monkeypatch.setenv("RANK", "0")
+    o._SEED_COUNTER[0] = 0
+    a = o.next_seed()
+    monkeypatch.setenv("RANK", "1")
+    o._SEED_COUNTER[0] = 0
+    b = o.next_seed()
+    assert a != b and 0 <= a < 2 ** 63 and 0 <= b < 2 ** 63
