@@ -5,10 +5,14 @@ seeded inputs, plus the golden vectors captured from the reference's own UNet bl
 Tolerances:
   fp32 mode (exact-fp32 MFMA) is the parity gate: rel = max|got-want| / max|want| <= 1e-4 forward, 1e-3 gradients
     (north_star: forward logits within 1e-3 rel of the CPU reference).
-  bf16 mode (bf16 operands + bf16 stored activations/gradients, fp32 accumulate) cannot meet 1e-3 (bf16 unit
-    round-off is 3.9e-3) and max-pool argmax flips move whole gradient entries, so it is checked with the relative
-    L2 error ||got-want|| / ||want|| <= 3e-2 forward, 0.3 gradients against the fp32 oracle; the bf16 kernels
-    themselves are pinned bit-exactly on integer-valued data in tests/test_gpu_exact.py.
+  bf16 mode (bf16 operands + bf16 stored activations/gradients, fp32 accumulate) cannot meet 1e-3 against the fp32 oracle
+    (bf16 unit round-off is 3.9e-3).  Each STAGE is therefore gated against the bf16-ROUNDED oracle
+    (oracle/hybrid_ref_bf16.py: the same algorithm, rounded to bf16 exactly where the kernels store or feed bf16, accumulated in
+    fp64), where only summation order is left: relative L2 error ||got-want|| / ||want|| <= BF16_FWD forward and <= BF16_GRAD on
+    every gradient (round 1 allowed 3e-2 / 0.3 against the fp32 oracle, which a wrong scale on a small tensor could slip
+    through).  Multi-stage compositions (the 2-layer encoder, the whole model) drift apart by bf16 noise whatever the
+    implementation (see the oracle's docstring), so they keep a looser bound; the bf16 contraction kernels themselves are pinned
+    bit-exactly on integer-valued data in tests/test_gpu_exact.py.
   Parameter gradients that are ~0 in the reference (e.g. the key bias: softmax is shift invariant) are compared
   against a floor of 1e-4 x the largest gradient magnitude in the module.
 """
@@ -22,9 +26,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import hybrid_ref as R  # noqa: E402
+from oracle import hybrid_ref_bf16 as RB  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = {"fp32": (1e-4, 1e-3), "bf16": (3e-2, 0.3)}
+BF16_FWD, BF16_GRAD = 2e-3, 2e-2          # one stage, against the bf16-rounded oracle
+TOL = {"fp32": (1e-4, 1e-3), "bf16": (BF16_FWD, BF16_GRAD)}
+_WORST = {}                               # what the bf16 comparisons actually measured (printed at the end of the module's run)
+
+
+def _note(kind, what, r):
+    k = (kind, what.split(" ")[0])
+    _WORST[k] = max(_WORST.get(k, 0.0), r)
+
 
 
 def P():
@@ -41,16 +54,26 @@ def rel(got, want, floor=0.0, l2=False):
     return (got - want).abs().max().item() / (denom if denom > 0 else 1.0)
 
 
-def check(got, want, tol, what, mode="fp32", floor=0.0):
+def check(got, want, tol, what, mode="fp32", floor=0.0, kind=None):
     r = rel(got, want, floor, l2=(mode == "bf16"))
+    if mode == "bf16" and kind:
+        _note(kind, what, r)
     assert math.isfinite(r) and r <= tol, f"{what}: {'L2' if mode == 'bf16' else 'max'} rel err {r:.3e} > {tol:.1e}"
 
 
-def check_param_grads(hip, ref, tol, mode):
+def check_param_grads(hip, ref, tol, mode, kind=None):
     hp = dict(hip.named_parameters())
     G = max(p.grad.abs().max().item() for p in ref.parameters())
     for n_, pr in ref.named_parameters():
-        check(hp[n_].grad, pr.grad, tol, "grad " + n_, mode, floor=1e-4 * G)
+        check(hp[n_].grad, pr.grad, tol, "grad:" + n_, mode, floor=1e-4 * G, kind=kind)
+
+
+def as_oracle(ref, mode):
+    """fp32 mode: the fp32 oracle module itself.  bf16 mode: its fp64 copy, to be driven through oracle/hybrid_ref_bf16.py."""
+    if mode == "fp32":
+        return ref
+    import copy
+    return copy.deepcopy(ref).double()
 
 
 def load_gold(name):
@@ -85,20 +108,28 @@ def test_conv_stage_matches_oracle(mode, ci, co, n, h, w, training):
     g = torch.Generator().manual_seed(1)
     x = torch.rand(n, ci, h, w, generator=g)
     r = torch.randn(n, co, h // 2, w // 2, generator=g)
-    xr = x.clone().requires_grad_(True)
-    yr = ref(xr)
-    (yr * r).sum().backward()
+    orc = as_oracle(ref, mode)
+    xr = x.clone().to(next(orc.parameters()).dtype).requires_grad_(True)
+    if mode == "bf16":
+        # the standalone module rounds its NCHW input to bf16 NHWC first (C_in > 4) / reads fp32 frames (first stage); r is rounded by the cast op
+        yr = RB.conv_stage(orc, "enc1", xr if ci <= 4 else RB.rb(xr), ci <= 4, training)
+        (yr * r.bfloat16().double()).sum().backward()
+        ref(x)                                   # the fp32 oracle's forward advances the running statistics compared below
+    else:
+        yr = ref(xr)
+        (yr * r).sum().backward()
     xh = x.cuda().requires_grad_(ci > 4)        # the first-stage kernel (C_in <= 4) reads the clip tensor and refuses to differentiate it
     yh = hip(xh)
     (yh * r.cuda()).sum().backward()
-    check(yh, yr, ftol, "pooled output", mode)
+    check(yh, yr, ftol, "pooled", mode, kind="conv stage fwd")
     bn_r, bn_h = ref.enc1norm1, hip.enc1norm1
-    check_param_grads(hip, ref, gtol, mode)
+    check_param_grads(hip, orc, gtol, mode, kind="conv stage bwd")
     if ci > 4:
-        check(xh.grad, xr.grad, gtol, "dx", mode)
+        check(xh.grad, xr.grad, gtol, "dx", mode, kind="conv stage bwd")
     if training:
-        check(bn_h.running_mean, bn_r.running_mean, ftol, "running_mean", mode)
-        check(bn_h.running_var, bn_r.running_var, ftol, "running_var", mode)
+        # (against the fp32 oracle in both modes: in bf16 mode the conv reads bf16-rounded inputs and weights)
+        check(bn_h.running_mean, bn_r.running_mean, 1e-4 if mode == "fp32" else 1e-2, "running_mean", mode)
+        check(bn_h.running_var, bn_r.running_var, 1e-4 if mode == "fp32" else 1e-2, "running_var", mode)
         assert int(bn_h.num_batches_tracked) == int(bn_r.num_batches_tracked) == 1
 
 
@@ -164,18 +195,24 @@ def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
         mask = (torch.rand(B, S, S) > 0.3).float()
         mask[:, :, 0] = 1
     r = torch.randn(B, S, D)
-    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
-    yr = ref(qr, kr, vr, mask)
-    (yr * r).sum().backward()
+    orc = as_oracle(ref, mode)
+    dt = next(orc.parameters()).dtype
+    qr, kr, vr = (t.clone().to(dt).requires_grad_(True) for t in (q, k, v))
+    if mode == "bf16":
+        yr = RB.mha(orc, qr, kr, vr, mask)
+        (yr * r.bfloat16().double()).sum().backward()
+    else:
+        yr = ref(qr, kr, vr, mask)
+        (yr * r).sum().backward()
     qh, kh, vh = (t.cuda().requires_grad_(True) for t in (q, k, v))
     yh = hip(qh, kh, vh, mask.cuda() if mask is not None else None)
     (yh * r.cuda()).sum().backward()
-    check(yh, yr, ftol, "mha out", mode)
+    check(yh, yr, ftol, "out", mode, kind="mha fwd")
     G = max(t.grad.abs().max().item() for t in (qr, kr, vr))
-    check(qh.grad, qr.grad, gtol, "dq_in", mode, floor=1e-4 * G)
-    check(kh.grad, kr.grad, gtol, "dk_in", mode, floor=1e-4 * G)
-    check(vh.grad, vr.grad, gtol, "dv_in", mode, floor=1e-4 * G)
-    check_param_grads(hip, ref, gtol, mode)
+    check(qh.grad, qr.grad, gtol, "dq_in", mode, floor=1e-4 * G, kind="mha bwd")
+    check(kh.grad, kr.grad, gtol, "dk_in", mode, floor=1e-4 * G, kind="mha bwd")
+    check(vh.grad, vr.grad, gtol, "dv_in", mode, floor=1e-4 * G, kind="mha bwd")
+    check_param_grads(hip, orc, gtol, mode, kind="mha bwd")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -197,15 +234,21 @@ def test_transformer_encoder_matches_oracle(mode, B, S, D, Hid, L, H, use_mask):
         mask = (torch.rand(B, S, S) > 0.3).float()
         mask[:, :, 0] = 1
     r = torch.randn(B, S, D)
-    xr = x.clone().requires_grad_(True)
-    yr = ref(xr, mask)
-    (yr * r).sum().backward()
+    orc = as_oracle(ref, mode)
+    xr = x.clone().to(next(orc.parameters()).dtype).requires_grad_(True)
+    if mode == "bf16":
+        yr = RB.encoder(orc, xr, mask)
+        (yr * r.bfloat16().double()).sum().backward()
+        ftol, gtol = 3 * L * ftol, 2 * L * gtol        # L layers = 6L rounding points in a row: the discrepancy compounds (oracle docstring)
+    else:
+        yr = ref(xr, mask)
+        (yr * r).sum().backward()
     xh = x.cuda().requires_grad_(True)
     yh = hip(xh, mask.cuda() if mask is not None else None)
     (yh * r.cuda()).sum().backward()
-    check(yh, yr, ftol, "encoder out", mode)
-    check(xh.grad, xr.grad, gtol, "dx", mode)
-    check_param_grads(hip, ref, gtol, mode)
+    check(yh, yr, ftol, "out", mode, kind=f"encoder L={L} fwd")
+    check(xh.grad, xr.grad, gtol, "dx", mode, kind=f"encoder L={L} bwd")
+    check_param_grads(hip, orc, gtol, mode, kind=f"encoder L={L} bwd")
 
 
 def test_attention_dropout_statistics_and_backward_consistency():
@@ -287,15 +330,26 @@ def test_full_model_logits_loss_and_grads_match_oracle(mode, cfg):
             for a in list(hip.encoder.attention_layers):
                 a.dropoutLayer.p = 0.0
         ref.zero_grad(); hip.zero_grad()
-        lr = ref(x)
-        loss_r = R.loss_fn(lr, y)
-        loss_r.backward()
+        if mode == "bf16":
+            # whole model = 4 conv stages + 2-3 encoder layers of rounding points in a row: bf16-noise-level drift between any two
+            # implementations (oracle docstring); gate at 2e-2 / 1e-1 against the rounded oracle (round 1: 3e-2 / 0.5 against fp32)
+            orc = as_oracle(ref, mode)
+            orc.train(training)
+            lr = RB.forward(orc, x.double())
+            loss_r = R.loss_fn(lr, y)
+            loss_r.backward()
+            ftol, gtol = 2e-2, 1e-1
+        else:
+            orc = ref
+            lr = ref(x)
+            loss_r = R.loss_fn(lr, y)
+            loss_r.backward()
         lh = hip(x.cuda())
         loss_h = loss_hip(lh, y.cuda())
         loss_h.backward()
-        check(lh, lr, ftol, f"logits (training={training})", mode)
+        check(lh, lr, ftol, f"logits (training={training})", mode, kind="whole model fwd")
         assert abs(loss_h.item() - loss_r.item()) <= ftol * max(1.0, abs(loss_r.item())), (loss_h.item(), loss_r.item())
-        check_param_grads(hip, ref, gtol if mode == "fp32" else 0.5, mode)
+        check_param_grads(hip, orc, gtol, mode, kind="whole model bwd")
 
 
 def test_frames_as_t1_and_state_dict_roundtrip():
@@ -329,3 +383,9 @@ def test_adamw_step_follows_oracle():
     hp = dict(hip.named_parameters())
     for n_, pr in ref.named_parameters():
         check(hp[n_], pr, 5e-3, n_)
+
+
+def test_zz_report_bf16_measured_errors():
+    """Not a check: prints the largest bf16-vs-rounded-oracle errors seen by this module's tests (run with -s)."""
+    for (kind, what), r in sorted(_WORST.items()):
+        print(f"bf16 worst {kind:28s} {what:12s} {r:.2e}")

@@ -400,41 +400,60 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
 }
 
 // MODE 4 finalize.  red = [S1: Cop x 48][G: 48 x 48, only tiles (i <= j) valid]; one thread per (co, k).
+// The finalize subtracts sums over all N*H*W positions that nearly cancel (S1 - m1*sum(P) is n*cov(dz, P) left over from terms of size
+// n*mean(dz)*mean(P)), so the workgroup partial rows are summed in DOUBLE and the tiny-matrix algebra below runs in double:
+// 36*Co threads, free.  (The fp32 partial rows themselves carry ~1e-6 relative error each, uncorrelated across the 512 of them.)
 template <typename T>
-__global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const float* __restrict__ red, const T* __restrict__ wp, const float* __restrict__ mi,
-                                                              const float* __restrict__ gamma, int training, float inv_count, int Co, int Ci,
+__global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __restrict__ red, const T* __restrict__ wp, const float* __restrict__ mi,
+                                                              const float* __restrict__ gamma, int training, double inv_count, int Co, int Ci,
                                                               int Cop, float* __restrict__ dw, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Co * 36) return;
     const int co = i / 36, k = i - co * 36;
-    const float* S1 = red + (long long)co * 48;
-    const float* G = red + (long long)Cop * 48;
+    const double* S1 = red + (long long)co * 48;
+    const double* G = red + (long long)Cop * 48;
     auto g_at = [&](int r, int c) { return (r / 16 <= c / 16) ? G[r * 48 + c] : G[c * 48 + r]; };      // symmetric
-    const float mean = mi[co], inv = mi[Cop + co];
-    const float sdz = S1[36];
-    float sdzy = 0.f, wg = 0.f;
+    const double mean = mi[co], inv = mi[Cop + co];
+    const double sdz = S1[36];
+    double sdzy = 0.0, wg = 0.0;
     for (int kk = 0; kk < 36; ++kk) {
-        const float w = to_f32<T>(wp[(long long)co * 64 + kk]);
-        sdzy = fmaf(w, S1[kk], sdzy);
-        wg = fmaf(w, g_at(kk, k), wg);
+        const double w = (double)to_f32<T>(wp[(long long)co * 64 + kk]);
+        sdzy = fma(w, S1[kk], sdzy);
+        wg = fma(w, g_at(kk, k), wg);
     }
-    const float sdzx = (sdzy - mean * sdz) * inv;              // sum dz * xhat
-    const float m1 = training ? sdz * inv_count : 0.f, m2 = training ? sdzx * inv_count : 0.f;
-    const float sp = g_at(k, 36);
-    const float v = gamma[co] * inv * (S1[k] - m1 * sp - m2 * inv * (wg - mean * sp));
+    const double sdzx = (sdzy - mean * sdz) * inv;             // sum dz * xhat
+    const double m1 = training ? sdz * inv_count : 0.0, m2 = training ? sdzx * inv_count : 0.0;
+    const double sp = g_at(k, 36);
+    const double v = (double)gamma[co] * inv * (S1[k] - m1 * sp - m2 * inv * (wg - mean * sp));
     const int tap = k >> 2, ci = k & 3;
-    if (ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = v;
+    if (ci < Ci) dw[((long long)co * Ci + ci) * 9 + tap] = (float)v;
     if (k == 0) {
-        if (dbeta) dbeta[co] = sdz;
-        if (dgamma) dgamma[co] = sdzx;
+        if (dbeta) dbeta[co] = (float)sdz;
+        if (dgamma) dgamma[co] = (float)sdzx;
     }
 }
 
-// fixed-order sum of the MODE 4 partial rows
-__global__ __launch_bounds__(1024) void s1_rows_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int G, long long n) {
-    long long i; float v;
-    if (rows_reduce_1024(part, G, n, i, v)) out[i] = v;
+// fixed-order DOUBLE sum of the MODE 4 partial rows: column i = sum_g part[g*n + i]; 256 threads = 32 columns x 8 row groups
+__global__ __launch_bounds__(256) void s1_rows_sum_kernel(const float* __restrict__ part, double* __restrict__ out, int G, long long n) {
+    __shared__ double red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    double a = 0.0;
+    if (i < n) {
+        int g = grp;
+        for (; g + 7 * 8 < G; g += 64) {                      // eight independent loads in flight (pure latency kernel), fixed add order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(long long)(g + j * 8) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (double)v[j];
+        }
+        for (; g < G; g += 8) a += (double)part[(long long)g * n + i];
+    }
+    red[grp][col] = a;
+    __syncthreads();
+    if (grp == 0 && i < n) out[i] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
 }
 
 // packed first-layer weights for this path: T [Cop][64], k = tap*4 + c
@@ -491,7 +510,7 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
 }
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 4) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
+    return al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 8) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
 }
 
 static int s1_grid(long long numTiles) {
@@ -548,7 +567,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
-    float* sums = (float*)ws;                    ws += al256(((size_t)Cop * 48 + 2304) * 4);      // reduced row [S1][G]
+    double* sums = (double*)ws;                  ws += al256(((size_t)Cop * 48 + 2304) * 8);      // reduced row [S1][G], double
     float* part = (float*)ws;
     if (packed_in) {
         wp = (T*)packed_in;                      // packed by the forward pass
@@ -558,7 +577,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
         HYB_LAUNCH_CHECK();
     }
     S1Args a{};
-    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = sums; a.dp = dpooled; a.part = part;
+    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = nullptr; a.dp = dpooled; a.part = part;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
     a.inv_count = 1.0f / (float)((long long)N * H * W);
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
@@ -573,10 +592,10 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const long long roww = (long long)Cop * 48 + 2304;
     int rc = s1_dispatch<T, 4>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(roww, 32)), dim3(1024), 0, st, part, sums, gx, roww);
+    hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(roww, 32)), dim3(256), 0, st, part, sums, gx, roww);
     HYB_LAUNCH_CHECK();
     hipLaunchKernelGGL(s1_bwd_finalize_kernel<T>, dim3(hyb_cdiv(Co * 36, 256)), dim3(256), 0, st, sums, wp, mean_invstd, gamma, training,
-                       a.inv_count, Co, Ci, Cop, dweight, dgamma, dbeta);
+                       1.0 / (double)((long long)N * H * W), Co, Ci, Cop, dweight, dgamma, dbeta);
     HYB_LAUNCH_CHECK();
     return 0;
 }
