@@ -238,6 +238,42 @@ int hyb_cross_entropy_fwd(const float* logits, const long long* target, float* l
 int hyb_cross_entropy_bwd(const float* logits, const long long* target, const float* dloss /* [1] */,
                           float* dlogits, int B, int C, void* stream);
 
+/* ---- model-level entry points: whole CNN backbone / whole temporal part in ONE call each way ---------------------------
+ * They chain the stage-level entry points above on the caller's stream; their purpose is host time (a training step is three
+ * operator calls each way), not different arithmetic: results are bit-identical to calling the stages one by one.
+ *
+ * hyb_backbone_*: `stages` conv stages, UNet.py:58-60 + UNet.py:13 each, in the order UNet.forward chains them (UNet.py:32-37).
+ *   channels [stages+1] = {C_in (<= 4: the clip frames are read as NCHW fp32), C_1, ..., C_stages}.
+ *   fwd params: HOST array of stages*5 device pointers {weight, gamma, beta, running_mean, running_var} (all read-only);
+ *   fwd outs:   HOST array of stages*6 device pointers {y_raw (unused for stage 0), pooled, scale_shift, mean_invstd, packed_bwd,
+ *               running_out [2][C_s] (training only; functional BatchNorm, see hyb_bn_finalize)}; pooled of stage s is the input
+ *               of stage s+1, sizes as in hyb_convstage_fwd.
+ *   bwd params: stages*2 {weight, gamma}; saved: stages*5 {y_raw, stage input (ignored for stage 0: x is passed), scale_shift,
+ *               mean_invstd, packed_bwd}; grads: stages*3 {dweight, dgamma, dbeta}.  The clip tensor gets no gradient. */
+size_t hyb_backbone_fwd_workspace(int dtype, int stages, const int* channels);
+int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params, int training,
+                     float momentum, float eps, int N, int H, int W, void* const* outs, void* workspace, size_t workspace_bytes,
+                     void* stream);
+size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* channels, int N, int H, int W);
+int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const float* x, const float* const* params,
+                     const void* const* saved, int training, int N, int H, int W, float* const* grads, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* hyb_temporal_*: frame tokens (global average pool over HW + Linear(C, D); composite's own) -> hyb_encoder_* (TransformerEncoder.pyc
+ *   src L110-126) -> head (mean over S + Linear(D, classes); composite's own).  h [B*S, HW, Cp] T is the last pooled map.
+ *   Saved by the caller for backward: feat [B*S, Cp] T, enc_saved (hyb_encoder_saved_bytes), enc_out [B,S,D] T; tok [B,S,D] T is scratch.
+ *   bwd writes every parameter gradient and dh [B*S, HW, Cp] T. */
+int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                     const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
+                     void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
+                     float attn_p, float layer_p, unsigned long long seed, void* stream);
+size_t hyb_temporal_bwd_workspace(int dtype, int B, int S, int HW, int Cp, int D, int Hid, int L, int H);
+int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, const float* const* enc_params, const float* head_w,
+                     const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
+                     float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
+                     int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
  * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
  * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]

@@ -126,10 +126,85 @@ def test_modules_dispatch_through_the_operators():
     with Spy():
         loss = P().HybridCrossEntropyLoss()(m(x), y)
         loss.backward()
+    hyb = [s.split(".")[1] for s in seen if s.startswith("hybrid.")]
+    assert hyb == ["backbone", "temporal", "cross_entropy", "cross_entropy_bwd", "temporal_bwd", "backbone_bwd"], hyb     # three calls each way
+    seen.clear()
+    m.fuse_model_ops = False                                       # one operator per stage (what standalone modules use)
+    with Spy():
+        loss = P().HybridCrossEntropyLoss()(m(x), y)
+        loss.backward()
     hyb = [s for s in seen if s.startswith("hybrid.")]
     for name in ("convstage", "token", "encoder", "head", "cross_entropy", "cross_entropy_bwd", "head_bwd", "encoder_bwd", "token_bwd", "convstage_bwd"):
         assert any(s.startswith(f"hybrid.{name}.") for s in hyb), (name, hyb)
     assert sum(s.startswith("hybrid.convstage.") for s in hyb) == 2 and sum(s.startswith("hybrid.convstage_bwd.") for s in hyb) == 2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("training", [True, False])
+def test_model_level_operators_equal_the_stage_operators_bitwise(mode, training):
+    """hybrid::backbone / hybrid::temporal chain the same kernels in C: logits, loss, every gradient and the BatchNorm buffers must be
+    bit-identical to the per-stage operator path."""
+    torch.manual_seed(5)
+    kw = dict(cnn_channels=(32, 64, 96), d_model=64, num_heads=4, num_layers=2, hidden_dim=128, dropout=0.1, compute_dtype=mode)
+    a, b = P().TransformerCNNHybrid(**kw).cuda(), P().TransformerCNNHybrid(**kw).cuda()
+    b.load_state_dict(a.state_dict())
+    b.fuse_model_ops = False
+    a.train(training); b.train(training)
+    x = torch.rand(3, 5, 3, 24, 40, device="cuda")
+    y = torch.tensor([1, 0, 7], device="cuda")
+    mask = (torch.rand(3, 5, 5, device="cuda") > 0.3).float()
+    mask[:, :, 0] = 1
+    o = ops()
+    res = []
+    for m in (a, b):
+        torch.manual_seed(11)
+        o._SEED_COUNTER[0] = 100                                    # same dropout seeds on both paths (one next_seed() call each)
+        logits = m(x, mask)
+        loss = P().HybridCrossEntropyLoss()(logits, y)
+        loss.backward()
+        res.append((logits.detach(), loss.detach()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), n
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
+def test_opcheck_model_level_operators(dt):
+    o = ops()
+    tdt = o.torch_dtype(dt)
+    torch.manual_seed(6)
+    N, B = 8, 2
+    chans = [3, 32, 64]
+    x = torch.rand(N, 3, 16, 24, device="cuda")
+    ws = [(torch.randn(chans[i + 1], chans[i], 3, 3, device="cuda") * 0.1).requires_grad_(True) for i in range(2)]
+    gs = [(torch.rand(c, device="cuda") + 0.5).requires_grad_(True) for c in chans[1:]]
+    bs = [torch.randn(c, device="cuda").requires_grad_(True) for c in chans[1:]]
+    rms = [torch.zeros(c, device="cuda") for c in chans[1:]]
+    rvs = [torch.ones(c, device="cuda") for c in chans[1:]]
+    for training in (True, False):
+        _opcheck(torch.ops.hybrid.backbone.default, (x, ws, gs, bs, rms, rvs, training, 0.1, 1e-5, dt))
+    res = torch.ops.hybrid.backbone(x, ws, gs, bs, rms, rvs, True, 0.1, 1e-5, dt)
+    st = o._backbone_unpack(res, 2)
+    saved = []
+    for s in range(2):
+        saved += [st[s][0].detach(), (st[s - 1][1] if s > 0 else st[s][0]).detach(), st[s][2].detach(), st[s][3].detach(), st[s][4].detach()]
+    _opcheck(torch.ops.hybrid.backbone_bwd.default, (torch.randn_like(res[0]).detach(), x, [w.detach() for w in ws], [g.detach() for g in gs], saved, True, dt))
+    # temporal part: B=4, S=8 keeps the saved blob free of alignment gaps (see test_opcheck_encoder_and_mha)
+    B, S, D, Hid, L, H = 4, 8, 32, 64, 2, 2
+    enc = P().TransformerEncoder(D, Hid, L, H, 0.1).cuda()
+    params = [p.detach().clone().requires_grad_(True) for p in enc._flat_params()]
+    h = torch.rand(B * S, 2, 3, 64, device="cuda").to(tdt).requires_grad_(True)
+    tw = (torch.randn(D, 64, device="cuda") * 0.1).requires_grad_(True)
+    tb = torch.randn(D, device="cuda").requires_grad_(True)
+    hw = (torch.randn(5, D, device="cuda") * 0.1).requires_grad_(True)
+    hb = torch.randn(5, device="cuda").requires_grad_(True)
+    args = (h, tw, tb, params, hw, hb, None, B, dt, Hid, L, H, 0.1, 0.1, 77)
+    _opcheck(torch.ops.hybrid.temporal.default, args)
+    logits, feat, saved_blob, enc_out = torch.ops.hybrid.temporal(*args)
+    _opcheck(torch.ops.hybrid.temporal_bwd.default, (torch.randn_like(logits).detach(), tw.detach(), [p.detach() for p in params], hw.detach(), None,
+                                                     feat.detach(), saved_blob, enc_out.detach(), 2, 3, dt, Hid, L, H, 0.1, 0.1, 77))
 
 
 def test_mask_is_validated_like_the_reference_would():

@@ -1,0 +1,134 @@
+// Model-level entry points: the whole CNN backbone and the whole temporal part (frame tokens -> TransformerEncoder -> head) as
+// ONE C call each way.  They only chain the stage-level entry points of this library on the caller's stream; what they save is
+// host time: a training step becomes three operator calls each way instead of seven, which keeps the step GPU-bound.
+//   hyb_backbone_{fwd,bwd} : `stages` x [Conv3x3 -> BatchNorm2d -> ReLU -> MaxPool2d]   (UNet.py:58-60 + UNet.py:13, UNet.py:32-37 order)
+//   hyb_temporal_{fwd,bwd} : global-average-pool + Linear frame token (composite's own) -> TransformerEncoder.forward
+//                            (TransformerEncoder.pyc src L110-126) -> mean over T + Linear head (composite's own)
+#include "hyb_common.h"
+
+namespace {
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
+#define HYB_TRY(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
+inline int padc(int c) { return (c + 31) / 32 * 32; }
+}  // namespace
+
+extern "C" size_t hyb_backbone_fwd_workspace(int dtype, int stages, const int* channels) {
+    if (stages < 1 || !channels) return 0;
+    size_t b = 0;
+    for (int s = 0; s < stages; ++s) b = smax(b, hyb_convstage_fwd_workspace(dtype, s == 0, s == 0 ? 0 : padc(channels[s]), padc(channels[s + 1])));
+    return al256(b);
+}
+
+extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params, int training,
+                                float momentum, float eps, int N, int H, int W, void* const* outs, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    HYB_CHECK_ARG(stages >= 1 && stages <= 16 && channels && x && params && outs && workspace && N > 0);
+    HYB_CHECK_ARG(channels[0] >= 1 && channels[0] <= 4);                  // the first stage reads NCHW fp32 frames directly
+    if (workspace_bytes < hyb_backbone_fwd_workspace(dtype, stages, channels)) return HYB_E_WORKSPACE;
+    const void* in = x;
+    int h = H, w = W;
+    for (int s = 0; s < stages; ++s) {
+        HYB_CHECK_ARG(h >= 2 && w >= 2);
+        const float* const* P = params + (size_t)s * 5;
+        void* const* O = outs + (size_t)s * 6;
+        const int Ci = channels[s], Co = channels[s + 1];
+        // the workspace is reused by every stage: the stages are ordered on the stream
+        HYB_TRY(hyb_convstage_fwd(dtype, s == 0, in, P[0], P[1], P[2], (float*)P[3], (float*)P[4], nullptr, training, momentum, eps, N, h, w, Ci,
+                                  s == 0 ? 0 : padc(Ci), Co, padc(Co), O[0], O[1], (float*)O[2], (float*)O[3], O[4], training ? (float*)O[5] : nullptr,
+                                  workspace, workspace_bytes, stream));
+        in = O[1];
+        h /= 2; w /= 2;
+    }
+    return 0;
+}
+
+extern "C" size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* channels, int N, int H, int W) {
+    if (stages < 1 || !channels || N <= 0) return 0;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    size_t stage_ws = 0, dx_bytes = 0;
+    int h = H, w = W;
+    for (int s = 0; s < stages; ++s) {
+        stage_ws = smax(stage_ws, hyb_convstage_bwd_workspace(dtype, s == 0, N, h, w, s == 0 ? 0 : padc(channels[s]), padc(channels[s + 1])));
+        if (s > 0) dx_bytes = smax(dx_bytes, (size_t)N * h * w * padc(channels[s]) * es);      // d(input of stage s) = d(pooled of stage s-1)
+        h /= 2; w /= 2;
+    }
+    return al256(stage_ws) + 2 * al256(dx_bytes);
+}
+
+extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const float* x, const float* const* params,
+                                const void* const* saved, int training, int N, int H, int W, float* const* grads, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(stages >= 1 && stages <= 16 && channels && dpooled_last && x && params && saved && grads && workspace && N > 0);
+    if (workspace_bytes < hyb_backbone_bwd_workspace(dtype, stages, channels, N, H, W)) return HYB_E_WORKSPACE;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    size_t stage_ws = 0, dx_bytes = 0;
+    int hs[17], wsz[17];
+    {
+        int h = H, w = W;
+        for (int s = 0; s < stages; ++s) {
+            hs[s] = h; wsz[s] = w;
+            stage_ws = smax(stage_ws, hyb_convstage_bwd_workspace(dtype, s == 0, N, h, w, s == 0 ? 0 : padc(channels[s]), padc(channels[s + 1])));
+            if (s > 0) dx_bytes = smax(dx_bytes, (size_t)N * h * w * padc(channels[s]) * es);
+            h /= 2; w /= 2;
+        }
+    }
+    char* ws = (char*)workspace;
+    void* dxbuf[2] = {ws + al256(stage_ws), ws + al256(stage_ws) + al256(dx_bytes)};
+    const void* dp = dpooled_last;
+    for (int s = stages - 1; s >= 0; --s) {
+        const float* const* P = params + (size_t)s * 2;          // weight, gamma
+        const void* const* S = saved + (size_t)s * 5;            // y_raw, stage input, scale_shift, mean_invstd, packed_bwd
+        float* const* G = grads + (size_t)s * 3;                 // dweight, dgamma, dbeta
+        const int Ci = channels[s], Co = channels[s + 1];
+        void* dx = s == 0 ? nullptr : dxbuf[s & 1];
+        HYB_TRY(hyb_convstage_bwd(dtype, s == 0, dp, s == 0 ? (const void*)x : S[1], S[0], P[0], P[1], (const float*)S[2], (const float*)S[3],
+                                  training, N, hs[s], wsz[s], Ci, s == 0 ? 0 : padc(Ci), Co, padc(Co), dx, G[0], G[1], G[2], S[4], ws, al256(stage_ws),
+                                  stream));
+        dp = dx;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" size_t hyb_temporal_bwd_workspace(int dtype, int B, int S, int HW, int Cp, int D, int Hid, int L, int H) {
+    if (B <= 0 || S <= 0 || D <= 0) return 0;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const size_t M = (size_t)B * S;
+    return al256(hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) + 2 * al256(M * D * es) + al256(M * Cp * es);
+}
+
+extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                                const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
+                                void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
+                                float attn_p, float layer_p, unsigned long long seed, void* stream) {
+    HYB_CHECK_ARG(h && token_w && enc_params && head_w && feat && tok && enc_saved && enc_out && logits && B > 0 && S > 0 && HW > 0);
+    const int N = B * S;
+    HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
+    HYB_TRY(hyb_linear_fwd(dtype, feat, Cp, token_w, token_b, tok, N, D, C, 0, stream));
+    HYB_TRY(hyb_encoder_fwd(dtype, tok, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, stream));
+    HYB_TRY(hyb_head_fwd(dtype, enc_out, head_w, head_b, logits, B, S, D, classes, stream));
+    return 0;
+}
+
+extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, const float* const* enc_params, const float* head_w,
+                                const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
+                                float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
+                                int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(dlogits && token_w && enc_params && head_w && feat && enc_saved && enc_out && dtoken_w && enc_grads && dhead_w && dh && workspace);
+    if (workspace_bytes < hyb_temporal_bwd_workspace(dtype, B, S, HW, Cp, D, Hid, L, H)) return HYB_E_WORKSPACE;
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const int N = B * S;
+    const size_t enc_ws = al256(hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H));
+    char* ws = (char*)workspace;
+    void* denc = ws + enc_ws;                                   // d(encoder output)
+    void* dtok = ws + enc_ws + al256((size_t)N * D * es);       // d(tokens)
+    void* dfeat = ws + enc_ws + 2 * al256((size_t)N * D * es);  // d(frame features), padded channels zero
+    HYB_TRY(hyb_head_bwd(dtype, enc_out, head_w, dlogits, denc, dhead_w, dhead_b, B, S, D, classes, stream));
+    HYB_TRY(hyb_encoder_bwd(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, ws, enc_ws, stream));
+    if (Cp > C) { hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)N * Cp * es, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, dtoken_w, dtoken_b, N, D, C, 0, nullptr, 0, stream));
+    HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));
+    return 0;
+}

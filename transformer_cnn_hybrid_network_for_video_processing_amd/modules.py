@@ -161,6 +161,7 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         self.encoder = TransformerEncoder(d_model, hidden_dim, num_layers, num_heads, dropout, compute_dtype)
         self.head = nn.Linear(d_model, num_classes)
         self._dt = ops.dtype_code(compute_dtype)
+        self.fuse_model_ops = True        # hybrid::backbone + hybrid::temporal (one C call each way) instead of one operator per stage
 
     def forward(self, x, mask=None):
         if x.dim() == 4:
@@ -172,6 +173,19 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
                                "(there is no CPU fallback)")
         B, T = x.shape[:2]
         f = x.reshape(B * T, *x.shape[2:]).float()                  # frames folded into the batch axis
+        stages = [getattr(self, f"encoder{i + 1}") for i in range(self.num_stages)]
+        enc = self.encoder
+        fused = (self.fuse_model_ops and self.in_channels <= 4 and enc.num_layers > 0 and self.token_proj.bias is not None and self.head.bias is not None
+                 and all(getattr(s, s._norm).track_running_stats and getattr(s, s._norm).running_mean is not None
+                         and getattr(s, s._norm).momentum == getattr(stages[0], stages[0]._norm).momentum
+                         and getattr(s, s._norm).eps == getattr(stages[0], stages[0]._norm).eps
+                         and s.training == self.training for s in stages))
+        if fused:
+            # two model-level operators (hybrid::backbone, hybrid::temporal): the same kernels as the stage operators below, chained in C
+            h = ops.backbone(f, [(getattr(s, s._conv).weight, getattr(s, s._norm)) for s in stages], self.training, self._dt)
+            attn_p = enc.attention_layers[0]._attn_p()
+            return ops.temporal(h, self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias, mask, B,
+                                self._dt, enc.hidden_dim, enc.num_layers, enc.num_heads, attn_p, float(enc.dropout), ops.next_seed())
         commit = []                                                  # running-statistics write-back of all stages: one multi-tensor copy
         if self.in_channels <= 4:
             h = self.encoder1.forward_nhwc(f, True, commit)

@@ -493,7 +493,7 @@ def _encoder_bwd(ctx, dout, dsaved_unused):
     saved, *rest = ctx.saved_tensors
     mask = rest.pop(0) if has_mask else None
     if dout is None:
-        return (None,) * 10
+        return (None, None, [None] * len(rest)) + (None,) * 7
     res = torch.ops.hybrid.encoder_bwd(dout, mask, [p.detach() for p in rest], saved, dt, hid, L, H, attn_p, layer_p, seed)
     return (res[0], None, list(res[1:])) + (None,) * 7
 
@@ -577,7 +577,7 @@ def _mha_bwd(ctx, dout, *unused):
     q_in, k_in, v_in, q, k, v, a, probs, *ps = ctx.saved_tensors
     dt, H, p_drop, seed = ctx.cfg
     if dout is None:
-        return (None,) * 9
+        return (None, None, None, None, [None] * len(ps), None, None, None, None)
     res = torch.ops.hybrid.mha_bwd(dout, q_in, k_in, v_in, q, k, v, a, probs, [p.detach() for p in ps], dt, H, p_drop, seed)
     return (res[0], res[1], res[2], None, list(res[3:]), None, None, None, None)
 
@@ -699,3 +699,270 @@ cross_entropy_op.register_autograd(_ce_bwd, setup_context=_ce_setup)
 
 def cross_entropy(logits, target):
     return torch.ops.hybrid.cross_entropy(logits, target)
+
+
+# ---------------------------------------------------------------------------------------------
+# model-level operators: the whole CNN backbone / the whole temporal part in one call each way (hyb_backbone_*, hyb_temporal_*).
+# Same kernels as the stage operators above, chained in C: a training step is three operator calls each way, which keeps the
+# host (Python dispatch ~50 us per operator call) off the critical path.
+# ---------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _int_array(vals):
+    return (_ct.c_int * len(vals))(*vals)
+
+
+def _backbone_geometry(x, weights):
+    N, Ci, H, W = x.shape
+    chans = [Ci] + [w.shape[0] for w in weights]
+    dims = []
+    h, w_ = H, W
+    for s in range(len(weights)):
+        dims.append((h, w_, 0 if s == 0 else pad_channels(chans[s]), pad_channels(chans[s + 1])))
+        h, w_ = h // 2, w_ // 2
+    return N, H, W, chans, dims
+
+
+@torch.library.custom_op("hybrid::backbone", mutates_args=())
+def backbone_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], betas: Sequence[Tensor], running_means: Sequence[Tensor],
+                running_vars: Sequence[Tensor], training: bool, momentum: float, eps: float, dt: int) -> List[Tensor]:
+    """All conv stages of the backbone on NCHW fp32 frames x [N, C_in <= 4, H, W].
+    -> [pooled_S, then per stage s: y_raw_s, pooled_s (s < S-1 only), scale_shift_s, mean_invstd_s, packed_bwd_s, running_out_s]
+    (functional BatchNorm: running_out_s [2, C_s] holds the updated statistics in training mode, empty otherwise)."""
+    _require_cuda(x, *weights)
+    x = x.contiguous()
+    S = len(weights)
+    N, H, W, chans, dims = _backbone_geometry(x, weights)
+    if chans[0] > 4:
+        raise RuntimeError("hybrid::backbone reads NCHW frames with C_in <= 4")
+    if dims[-1][0] < 2 or dims[-1][1] < 2:
+        raise RuntimeError(f"frames of {H}x{W} are too small for {S} conv stages (each needs H, W >= 2)")
+    dev, tdt = x.device, _TORCH_DTYPE[dt]
+    per_stage, pooled = [], None
+    params, outs = [], []
+    for s in range(S):
+        h, w_, Cip, Cop = dims[s]
+        Co = chans[s + 1]
+        y_raw = torch.empty(0 if s == 0 else (N, h, w_, Cop), dtype=tdt, device=dev)
+        pooled = torch.empty(N, h // 2, w_ // 2, Cop, dtype=tdt, device=dev)
+        ss = torch.empty(2, Cop, dtype=torch.float32, device=dev)
+        mi = torch.empty(2, Cop, dtype=torch.float32, device=dev)
+        pk = torch.empty(_query("hyb_convstage_packed_bwd_elems", int(s == 0), Cip, Cop), dtype=tdt, device=dev)
+        ro = torch.empty((2, Co) if training else (0,), dtype=torch.float32, device=dev)
+        per_stage.append((y_raw, pooled, ss, mi, pk, ro))
+        params += [weights[s].contiguous().data_ptr(), gammas[s].contiguous().data_ptr(), betas[s].contiguous().data_ptr(),
+                   running_means[s].contiguous().data_ptr(), running_vars[s].contiguous().data_ptr()]
+        outs += [None if s == 0 else y_raw.data_ptr(), pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(), pk.data_ptr(), ro.data_ptr() if training else None]
+    ch = _int_array(chans)
+    ws = _ws(_query("hyb_backbone_fwd_workspace", dt, S, tuple(chans)), dev)
+    lib.call("hyb_backbone_fwd", dt, S, ch, x.data_ptr(), ptr_array(params), int(training), float(momentum), float(eps), N, H, W,
+             ptr_array(outs), ws.data_ptr(), ws.numel(), _stream())
+    res = [pooled]
+    for s, (y_raw, p, ss, mi, pk, ro) in enumerate(per_stage):
+        res += [y_raw] + ([p] if s < S - 1 else []) + [ss, mi, pk, ro]
+    return res
+
+
+@backbone_op.register_fake
+def _(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt):
+    S = len(weights)
+    N, H, W, chans, dims = _backbone_geometry(x, weights)
+    tdt = _TORCH_DTYPE[dt]
+    res, last = [], None
+    for s in range(S):
+        h, w_, Cip, Cop = dims[s]
+        last = x.new_empty((N, h // 2, w_ // 2, Cop), dtype=tdt)
+        res += [x.new_empty((0,) if s == 0 else (N, h, w_, Cop), dtype=tdt)] + ([last] if s < S - 1 else []) + [
+            x.new_empty((2, Cop), dtype=torch.float32), x.new_empty((2, Cop), dtype=torch.float32),
+            x.new_empty((_query("hyb_convstage_packed_bwd_elems", int(s == 0), Cip, Cop),), dtype=tdt),
+            x.new_empty((2, chans[s + 1]) if training else (0,), dtype=torch.float32)]
+    return [last] + res
+
+
+def _backbone_unpack(res, S):
+    """[pooled_S, ...] -> per stage (y_raw, pooled, scale_shift, mean_invstd, packed_bwd, running_out)."""
+    out, i = [], 1
+    for s in range(S):
+        y_raw = res[i]; i += 1
+        if s < S - 1:
+            p = res[i]; i += 1
+        else:
+            p = res[0]
+        out.append((y_raw, p, res[i], res[i + 1], res[i + 2], res[i + 3]))
+        i += 4
+    return out
+
+
+@torch.library.custom_op("hybrid::backbone_bwd", mutates_args=())
+def backbone_bwd_op(dpooled: Tensor, x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], saved: Sequence[Tensor], training: bool,
+                    dt: int) -> List[Tensor]:
+    """saved: per stage (y_raw, stage input [placeholder for stage 0], scale_shift, mean_invstd, packed_bwd).
+    -> per stage (dweight, dgamma, dbeta), flattened."""
+    _require_cuda(dpooled, x)
+    S = len(weights)
+    N, H, W, chans, dims = _backbone_geometry(x, weights)
+    dev = x.device
+    dpooled = dpooled.contiguous()
+    grads, gptr, pptr, sptr = [], [], [], []
+    for s in range(S):
+        dw = torch.empty_like(weights[s], memory_format=torch.contiguous_format)
+        dg = torch.empty(chans[s + 1], dtype=torch.float32, device=dev)
+        db = torch.empty(chans[s + 1], dtype=torch.float32, device=dev)
+        grads += [dw, dg, db]
+        gptr += [dw.data_ptr(), dg.data_ptr(), db.data_ptr()]
+        pptr += [weights[s].contiguous().data_ptr(), gammas[s].contiguous().data_ptr()]
+        sv = saved[5 * s:5 * s + 5]
+        sptr += [None if s == 0 else sv[0].data_ptr(), None if s == 0 else sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), sv[4].data_ptr()]
+    ws = _ws(_query("hyb_backbone_bwd_workspace", dt, S, tuple(chans), N, H, W), dev)
+    lib.call("hyb_backbone_bwd", dt, S, _int_array(chans), dpooled.data_ptr(), x.data_ptr(), ptr_array(pptr), ptr_array(sptr), int(training),
+             N, H, W, ptr_array(gptr), ws.data_ptr(), ws.numel(), _stream())
+    return grads
+
+
+@backbone_bwd_op.register_fake
+def _(dpooled, x, weights, gammas, saved, training, dt):
+    res = []
+    for w in weights:
+        res += [torch.empty_like(w, memory_format=torch.contiguous_format), x.new_empty((w.shape[0],), dtype=torch.float32),
+                x.new_empty((w.shape[0],), dtype=torch.float32)]
+    return res
+
+
+def _backbone_setup(ctx, inputs, output):
+    x, weights, gammas, betas, rms, rvs, training, momentum, eps, dt = inputs
+    if ctx.needs_input_grad[0]:
+        raise RuntimeError("the first conv stage does not compute a gradient for its input (the clip tensor): pass clips with "
+                           "requires_grad=False (training data never needs one); a silent None would be wrong")
+    S = len(weights)
+    st = _backbone_unpack(output, S)
+    saved = []
+    for s in range(S):
+        y_raw, p, ss, mi, pk, ro = st[s]
+        saved += [y_raw, (st[s - 1][1] if s > 0 else y_raw), ss, mi, pk]
+    ctx.save_for_backward(x, *weights, *gammas, *saved)
+    ctx.cfg = (S, bool(training), dt)
+    ctx.set_materialize_grads(False)
+
+
+def _backbone_bwd(ctx, grads_out):
+    S, training, dt = ctx.cfg
+    t = ctx.saved_tensors
+    x, weights, gammas, saved = t[0], list(t[1:1 + S]), list(t[1 + S:1 + 2 * S]), list(t[1 + 2 * S:])
+    dpooled = grads_out[0]
+    none = [None] * S
+    if dpooled is None:
+        return (None, none, none, none, none, none, None, None, None, None)
+    g = torch.ops.hybrid.backbone_bwd(dpooled, x, [w.detach() for w in weights], [v.detach() for v in gammas], saved, training, dt)
+    return (None, [g[3 * s] for s in range(S)], [g[3 * s + 1] for s in range(S)], [g[3 * s + 2] for s in range(S)], none, none, None, None, None, None)
+
+
+backbone_op.register_autograd(_backbone_bwd, setup_context=_backbone_setup)
+
+
+def backbone(x, stages, training, dt):
+    """stages: list of (conv.weight, bn) pairs.  Applies nn.BatchNorm2d's buffer updates after the functional operator."""
+    bns = [bn for _, bn in stages]
+    res = torch.ops.hybrid.backbone(x, [w for w, _ in stages], [bn.weight for bn in bns], [bn.bias for bn in bns],
+                                    [bn.running_mean for bn in bns], [bn.running_var for bn in bns], bool(training), float(bns[0].momentum),
+                                    float(bns[0].eps), int(dt))
+    if training:
+        st = _backbone_unpack(res, len(stages))
+        commit_running_stats([(bn.running_mean, bn.running_var, bn.num_batches_tracked, st[s][5]) for s, bn in enumerate(bns)])
+    return res[0]
+
+
+@torch.library.custom_op("hybrid::temporal", mutates_args=())
+def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, head_b: Tensor, mask: Optional[Tensor],
+                B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """h [B*S, Hh, Ww, Cp] T (last pooled map) -> (logits [B, classes] fp32, feat, enc_saved, enc_out); the last three are saved for backward."""
+    _require_cuda(h, token_w, head_w, *enc_params)
+    h = h.contiguous()
+    N, Hh, Ww, Cp = h.shape
+    S = N // B
+    D, C = token_w.shape
+    classes = head_w.shape[0]
+    _check_attention_limits(S, D, H)
+    dev, tdt = h.device, _TORCH_DTYPE[dt]
+    feat = torch.empty(N, Cp, dtype=tdt, device=dev)
+    tok = torch.empty(B, S, D, dtype=tdt, device=dev)
+    enc_out = torch.empty(B, S, D, dtype=tdt, device=dev)
+    saved = _ws(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), dev)
+    logits = torch.empty(B, classes, dtype=torch.float32, device=dev)
+    ps = [p.contiguous() for p in enc_params]
+    lib.call("hyb_temporal_fwd", dt, h.data_ptr(), token_w.contiguous().data_ptr(), token_b.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
+             head_w.contiguous().data_ptr(), head_b.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), tok.data_ptr(), saved.data_ptr(),
+             enc_out.data_ptr(), logits.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes, float(attn_p), float(layer_p), seed, _stream())
+    return logits, feat, saved, enc_out
+
+
+@temporal_op.register_fake
+def _(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
+    N, Hh, Ww, Cp = h.shape
+    S, D = N // B, token_w.shape[0]
+    tdt = _TORCH_DTYPE[dt]
+    return (h.new_empty((B, head_w.shape[0]), dtype=torch.float32), h.new_empty((N, Cp), dtype=tdt),
+            h.new_empty((max(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), 256),), dtype=torch.uint8), h.new_empty((B, S, D), dtype=tdt))
+
+
+@torch.library.custom_op("hybrid::temporal_bwd", mutates_args=())
+def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, mask: Optional[Tensor], feat: Tensor,
+                    saved: Tensor, enc_out: Tensor, Hh: int, Ww: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float,
+                    seed: int) -> List[Tensor]:
+    """-> [dh, dtoken_w, dtoken_b, dhead_w, dhead_b, denc_param_0, ...]"""
+    _require_cuda(dlogits, feat)
+    B, S, D = enc_out.shape
+    N, Cp = feat.shape
+    C = token_w.shape[1]
+    classes = head_w.shape[0]
+    dev, tdt = feat.device, _TORCH_DTYPE[dt]
+    dlogits = dlogits.contiguous().float()
+    ps = [p.contiguous() for p in enc_params]
+    grads = [torch.empty_like(p) for p in ps]
+    dh = torch.empty(N, Hh, Ww, Cp, dtype=tdt, device=dev)
+    dtw = torch.empty_like(token_w, memory_format=torch.contiguous_format)
+    dtb = torch.empty(D, dtype=torch.float32, device=dev)
+    dhw = torch.empty_like(head_w, memory_format=torch.contiguous_format)
+    dhb = torch.empty(classes, dtype=torch.float32, device=dev)
+    ws = _ws(_query("hyb_temporal_bwd_workspace", dt, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
+    lib.call("hyb_temporal_bwd", dt, dlogits.data_ptr(), token_w.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
+             head_w.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), saved.data_ptr(), enc_out.data_ptr(), dtw.data_ptr(), dtb.data_ptr(),
+             ptr_array([g.data_ptr() for g in grads]), dhw.data_ptr(), dhb.data_ptr(), dh.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes,
+             float(attn_p), float(layer_p), seed, ws.data_ptr(), ws.numel(), _stream())
+    return [dh, dtw, dtb, dhw, dhb] + grads
+
+
+@temporal_bwd_op.register_fake
+def _(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed):
+    N, Cp = feat.shape
+    c = lambda t: torch.empty_like(t, memory_format=torch.contiguous_format)
+    return [feat.new_empty((N, Hh, Ww, Cp)), c(token_w), feat.new_empty((token_w.shape[0],), dtype=torch.float32), c(head_w),
+            feat.new_empty((head_w.shape[0],), dtype=torch.float32)] + [c(p) for p in enc_params]
+
+
+def _temporal_setup(ctx, inputs, output):
+    h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed = inputs
+    logits, feat, saved, enc_out = output
+    ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, *([mask] if mask is not None else []), *enc_params)
+    ctx.cfg = (mask is not None, h.shape[1], h.shape[2], dt, hid, L, H, attn_p, layer_p, seed)
+    ctx.set_materialize_grads(False)
+
+
+def _temporal_bwd(ctx, dlogits, *unused):
+    has_mask, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
+    token_w, head_w, feat, saved, enc_out, *rest = ctx.saved_tensors
+    mask = rest.pop(0) if has_mask else None
+    if dlogits is None:
+        return (None, None, None, [None] * len(rest), None, None) + (None,) * 9
+    g = torch.ops.hybrid.temporal_bwd(dlogits, token_w.detach(), [p.detach() for p in rest], head_w.detach(), mask, feat, saved, enc_out, Hh, Ww,
+                                      dt, hid, L, H, attn_p, layer_p, seed)
+    return (g[0], g[1], g[2], list(g[5:]), g[3], g[4]) + (None,) * 9
+
+
+temporal_op.register_autograd(_temporal_bwd, setup_context=_temporal_setup)
+
+
+def temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
+    S = h.shape[0] // B
+    return torch.ops.hybrid.temporal(h, token_w, token_b, list(enc_params), head_w, head_b, check_mask(mask, B, S, h.device), B, dt, hid, L, H,
+                                     float(attn_p), float(layer_p), seed)[0]
