@@ -1,10 +1,18 @@
-"""The hot path as custom torch operators: ``torch.ops.hybrid.*`` (torch.library.custom_op + register_autograd +
-register_fake) over the C ABI of include/hybrid_hip.h.
+"""The hot path as custom torch operators: ``torch.ops.hybrid.*`` over the C ABI of include/hybrid_hip.h.
 
 Every operator enqueues HIP kernels on torch's current stream through ctypes; tensors only provide device memory.
-Forward operators return the tensors their backward needs as extra outputs (saved by ``setup_context``); each backward is
-itself an operator (``hybrid::*_bwd``), so the whole path is visible to the dispatcher, has fake (meta) implementations for
-shape inference and passes ``torch.library.opcheck``.  There is no eager/CPU implementation behind them: a CPU tensor raises.
+Forward operators return the tensors their backward needs as extra outputs; each backward is itself an operator
+(``hybrid::*_bwd``), so the whole path is visible to the dispatcher, has fake (meta) implementations for shape inference
+(``torch.library.register_fake``) and passes ``torch.library.opcheck``.  There is no eager/CPU implementation behind them:
+a CPU tensor raises.
+
+Registration uses torch.library's low-level interface (``Library.define`` / ``Library.impl`` + ``register_fake``) with a
+hand-written ``torch.autograd.Function`` on the Autograd dispatch key of every differentiable operator, NOT the
+``custom_op`` / ``register_autograd`` decorators: those were measured first (round 2) and cost 120 us per forward call and
+430 us per forward+backward pair for an operator with a 28-tensor parameter list (generic pytree flattening, schema
+re-checks, a dynamo-disable wrapper per call) against 36 / 230 us for this form -- with ~1.6 ms of GPU work per step that
+difference decides whether the step is GPU-bound.  What the dispatcher sees is the same: a schema, a backend kernel, a
+fake kernel and an autograd kernel per operator.
 
     hybrid::convstage        Conv3x3 -> BatchNorm2d -> ReLU -> MaxPool2d(2,2)   (UNet.py:58-60 + UNet.py:13)
     hybrid::token            global average pool + Linear(C, d)                  (composite's own glue)
@@ -24,6 +32,18 @@ from torch import Tensor
 from ._lib import HYB_BF16, HYB_F32, lib, ptr_array
 
 _TORCH_DTYPE = {HYB_F32: torch.float32, HYB_BF16: torch.bfloat16}
+_LIB = torch.library.Library("hybrid", "DEF")
+_below_autograd = torch._C._AutoDispatchBelowAutograd
+
+
+def _define(name, schema, impl, fake, autograd=None):
+    """One operator: schema, backend kernel (every device: CPU tensors get the "no CPU fallback" error from _require_cuda),
+    fake kernel, and -- for differentiable operators -- the Autograd-key kernel wrapping a torch.autograd.Function."""
+    _LIB.define(name + schema)
+    _LIB.impl(name, impl, "CompositeExplicitAutograd")
+    torch.library.register_fake("hybrid::" + name, fake)
+    if autograd is not None:
+        _LIB.impl(name, autograd, "Autograd")
 _SEED_COUNTER = [0]
 _SEED_MASK = 0x7FFFFFFFFFFFFFFF          # operator schemas carry ints as int64
 
@@ -62,8 +82,10 @@ def _ws(nbytes, device):
 
 @functools.lru_cache(maxsize=None)
 def _query(name, *args):
-    """Size queries are pure host functions of their integer arguments: ask the library once per shape."""
-    return lib.query(name, *args)
+    """Size queries are pure host functions of their integer arguments: ask the library once per shape.  A tuple argument is
+    passed as a C int array."""
+    import ctypes
+    return lib.query(name, *[(ctypes.c_int * len(a))(*a) if isinstance(a, tuple) else a for a in args])
 
 
 def _rank():
@@ -103,7 +125,6 @@ def check_mask(mask, B, S, device):
 # ---------------------------------------------------------------------------------------------
 # layout / cast glue (standalone module use; the fused model path needs neither)
 # ---------------------------------------------------------------------------------------------
-@torch.library.custom_op("hybrid::nchw_to_nhwc", mutates_args=())
 def nchw_to_nhwc_op(x: Tensor, dt: int, cp: int) -> Tensor:
     _require_cuda(x)
     x = x.contiguous().float()
@@ -113,13 +134,11 @@ def nchw_to_nhwc_op(x: Tensor, dt: int, cp: int) -> Tensor:
     return out
 
 
-@nchw_to_nhwc_op.register_fake
-def _(x, dt, cp):
+def nchw_to_nhwc_fake(x, dt, cp):
     N, C, H, W = x.shape
     return x.new_empty((N, H, W, cp), dtype=_TORCH_DTYPE[dt])
 
 
-@torch.library.custom_op("hybrid::nhwc_to_nchw", mutates_args=())
 def nhwc_to_nchw_op(x: Tensor, dt: int, C: int) -> Tensor:
     _require_cuda(x)
     x = x.contiguous()
@@ -129,30 +148,19 @@ def nhwc_to_nchw_op(x: Tensor, dt: int, C: int) -> Tensor:
     return out
 
 
-@nhwc_to_nchw_op.register_fake
-def _(x, dt, C):
+def nhwc_to_nchw_fake(x, dt, C):
     N, H, W, cp = x.shape
     return x.new_empty((N, C, H, W), dtype=torch.float32)
 
 
-def _nchw_to_nhwc_setup(ctx, inputs, output):
-    ctx.dt, ctx.C = inputs[1], inputs[0].shape[1]
 
 
-def _nchw_to_nhwc_bwd(ctx, g):
-    return torch.ops.hybrid.nhwc_to_nchw(g, ctx.dt, ctx.C), None, None
 
 
-def _nhwc_to_nchw_setup(ctx, inputs, output):
-    ctx.dt, ctx.cp = inputs[1], inputs[0].shape[3]
 
 
-def _nhwc_to_nchw_bwd(ctx, g):
-    return torch.ops.hybrid.nchw_to_nhwc(g, ctx.dt, ctx.cp), None, None
 
 
-nchw_to_nhwc_op.register_autograd(_nchw_to_nhwc_bwd, setup_context=_nchw_to_nhwc_setup)
-nhwc_to_nchw_op.register_autograd(_nhwc_to_nchw_bwd, setup_context=_nhwc_to_nchw_setup)
 
 
 def nchw_to_nhwc(x, dt, cp):
@@ -163,7 +171,6 @@ def nhwc_to_nchw(x, dt, C):
     return torch.ops.hybrid.nhwc_to_nchw(x, dt, C)
 
 
-@torch.library.custom_op("hybrid::cast", mutates_args=())
 def cast_op(x: Tensor, dt: int, to_t: bool) -> Tensor:
     """fp32 <-> T with the library's own cast kernels (differentiable)."""
     _require_cuda(x)
@@ -178,20 +185,12 @@ def cast_op(x: Tensor, dt: int, to_t: bool) -> Tensor:
     return out
 
 
-@cast_op.register_fake
-def _(x, dt, to_t):
+def cast_fake(x, dt, to_t):
     return x.new_empty(x.shape, dtype=_TORCH_DTYPE[dt] if to_t else torch.float32)
 
 
-def _cast_setup(ctx, inputs, output):
-    ctx.dt, ctx.to_t = inputs[1], inputs[2]
 
 
-def _cast_bwd(ctx, g):
-    return torch.ops.hybrid.cast(g, ctx.dt, not ctx.to_t), None, None
-
-
-cast_op.register_autograd(_cast_bwd, setup_context=_cast_setup)
 
 
 def to_compute(x, dt):
@@ -216,7 +215,6 @@ def _convstage_dims(x, weight, first):
     return N, H, W, Ci, Cip, Co, Cop
 
 
-@torch.library.custom_op("hybrid::convstage", mutates_args=())
 def convstage_op(x: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
                  training: bool, momentum: float, eps: float, dt: int, first: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (pooled, y_raw, scale_shift, mean_invstd, packed_bwd, running_out).  FUNCTIONAL, like aten's
@@ -256,8 +254,7 @@ def convstage_op(x: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, running
     return pooled, y_raw, scale_shift, mean_invstd, packed_bwd, running_out
 
 
-@convstage_op.register_fake
-def _(x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, dt, first):
+def convstage_fake(x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, dt, first):
     N, H, W, Ci, Cip, Co, Cop = _convstage_dims(x, weight, first)
     tdt = _TORCH_DTYPE[dt]
     track = running_mean is not None and running_var is not None
@@ -268,7 +265,6 @@ def _(x, weight, gamma, beta, running_mean, running_var, training, momentum, eps
             x.new_empty((2, Co) if training and track else (0,), dtype=torch.float32))
 
 
-@torch.library.custom_op("hybrid::convstage_bwd", mutates_args=())
 def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, weight: Tensor, gamma: Tensor, scale_shift: Tensor, mean_invstd: Tensor,
                      packed_bwd: Tensor, training: bool, dt: int, first: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """-> (dx, dweight, dgamma, dbeta); dx is an empty placeholder for the first stage (the clip tensor gets no gradient)."""
@@ -288,36 +284,14 @@ def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, weight: Tensor, 
     return dx, dw, dgamma, dbeta
 
 
-@convstage_bwd_op.register_fake
-def _(dpooled, x, y_raw, weight, gamma, scale_shift, mean_invstd, packed_bwd, training, dt, first):
+def convstage_bwd_fake(dpooled, x, y_raw, weight, gamma, scale_shift, mean_invstd, packed_bwd, training, dt, first):
     N, H, W, Ci, Cip, Co, Cop = _convstage_dims(x, weight, first)
     return (x.new_empty((0,) if first else (N, H, W, Cip), dtype=_TORCH_DTYPE[dt]), torch.empty_like(weight, memory_format=torch.contiguous_format),
             x.new_empty((Co,), dtype=torch.float32), x.new_empty((Co,), dtype=torch.float32))
 
 
-def _convstage_setup(ctx, inputs, output):
-    x, weight, gamma, beta, rm, rv, training, momentum, eps, dt, first = inputs
-    if first and ctx.needs_input_grad[0]:
-        raise RuntimeError("the first conv stage does not compute a gradient for its input (the clip tensor): pass clips with "
-                           "requires_grad=False (training data never needs one); a silent None would be wrong")
-    pooled, y_raw, scale_shift, mean_invstd, packed_bwd, running_out = output
-    ctx.mark_non_differentiable(running_out)
-    ctx.save_for_backward(x, y_raw, weight, gamma, scale_shift, mean_invstd, packed_bwd)
-    ctx.cfg = (bool(training), dt, bool(first))
-    ctx.set_materialize_grads(False)
 
 
-def _convstage_bwd(ctx, dpooled, *unused):
-    x, y_raw, weight, gamma, scale_shift, mean_invstd, packed_bwd = ctx.saved_tensors
-    training, dt, first = ctx.cfg
-    if dpooled is None:
-        return (None,) * 11
-    dx, dw, dgamma, dbeta = torch.ops.hybrid.convstage_bwd(dpooled, x, y_raw, weight.detach(), gamma.detach(), scale_shift, mean_invstd,
-                                                           packed_bwd, training, dt, first)
-    return (None if first else dx, dw, dgamma, dbeta) + (None,) * 7
-
-
-convstage_op.register_autograd(_convstage_bwd, setup_context=_convstage_setup)
 
 
 def convstage(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, dt, first, commit=None):
@@ -353,7 +327,6 @@ def commit_running_stats(entries):
 # ---------------------------------------------------------------------------------------------
 # frame token: global average pool + Linear(C, d)
 # ---------------------------------------------------------------------------------------------
-@torch.library.custom_op("hybrid::token", mutates_args=())
 def token_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dt: int) -> Tuple[Tensor, Tensor]:
     """x [N,Hh,Ww,Cp] -> (tok [N,d], feat [N,Cp] saved)."""
     _require_cuda(x, weight)
@@ -370,13 +343,11 @@ def token_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dt: int) -> Tupl
     return tok, feat
 
 
-@token_op.register_fake
-def _(x, weight, bias, dt):
+def token_fake(x, weight, bias, dt):
     N, Hh, Ww, Cp = x.shape
     return x.new_empty((N, weight.shape[0]), dtype=_TORCH_DTYPE[dt]), x.new_empty((N, Cp), dtype=_TORCH_DTYPE[dt])
 
 
-@torch.library.custom_op("hybrid::token_bwd", mutates_args=())
 def token_bwd_op(dtok: Tensor, feat: Tensor, weight: Tensor, Hh: int, Ww: int, has_bias: bool, dt: int) -> Tuple[Tensor, Tensor, Tensor]:
     _require_cuda(dtok, feat)
     N, Cp = feat.shape
@@ -394,30 +365,14 @@ def token_bwd_op(dtok: Tensor, feat: Tensor, weight: Tensor, Hh: int, Ww: int, h
     return dx, dw, db
 
 
-@token_bwd_op.register_fake
-def _(dtok, feat, weight, Hh, Ww, has_bias, dt):
+def token_bwd_fake(dtok, feat, weight, Hh, Ww, has_bias, dt):
     N, Cp = feat.shape
     return (feat.new_empty((N, Hh, Ww, Cp)), torch.empty_like(weight, memory_format=torch.contiguous_format),
             feat.new_empty((weight.shape[0] if has_bias else 0,), dtype=torch.float32))
 
 
-def _token_setup(ctx, inputs, output):
-    x, weight, bias, dt = inputs
-    ctx.save_for_backward(output[1], weight)
-    ctx.cfg = (x.shape[1], x.shape[2], bias is not None, dt)
-    ctx.set_materialize_grads(False)
 
 
-def _token_bwd(ctx, dtok, dfeat_unused):
-    feat, weight = ctx.saved_tensors
-    Hh, Ww, has_bias, dt = ctx.cfg
-    if dtok is None:
-        return None, None, None, None
-    dx, dw, db = torch.ops.hybrid.token_bwd(dtok, feat, weight.detach(), Hh, Ww, has_bias, dt)
-    return dx, dw, (db if has_bias else None), None
-
-
-token_op.register_autograd(_token_bwd, setup_context=_token_setup)
 
 
 def token(x, weight, bias, dt):
@@ -434,7 +389,6 @@ def _check_attention_limits(S, D, H):
         raise RuntimeError(f"temporal attention kernel supports head widths that are multiples of 8 up to 128 (got {D}/{H})")
 
 
-@torch.library.custom_op("hybrid::encoder", mutates_args=())
 def encoder_op(x: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], dt: int, hid: int, L: int, H: int, attn_p: float,
                layer_p: float, seed: int) -> Tuple[Tensor, Tensor]:
     """x [B,S,D] T, mask fp32 [B,S,S] or None, params = L*14 fp32 tensors (order: include/hybrid_hip.h) -> (out, saved blob)."""
@@ -451,14 +405,12 @@ def encoder_op(x: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], dt: 
     return out, saved
 
 
-@encoder_op.register_fake
-def _(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
+def encoder_fake(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
     B, S, D = x.shape
     return torch.empty_like(x, memory_format=torch.contiguous_format), x.new_empty((max(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), 256),),
                                                                                     dtype=torch.uint8)
 
 
-@torch.library.custom_op("hybrid::encoder_bwd", mutates_args=())
 def encoder_bwd_op(dout: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], saved: Tensor, dt: int, hid: int, L: int, H: int,
                    attn_p: float, layer_p: float, seed: int) -> List[Tensor]:
     """-> [dx, dparam_0, ..., dparam_{14L-1}]"""
@@ -476,29 +428,12 @@ def encoder_bwd_op(dout: Tensor, mask: Optional[Tensor], params: Sequence[Tensor
     return [dx] + grads
 
 
-@encoder_bwd_op.register_fake
-def _(dout, mask, params, saved, dt, hid, L, H, attn_p, layer_p, seed):
+def encoder_bwd_fake(dout, mask, params, saved, dt, hid, L, H, attn_p, layer_p, seed):
     return [torch.empty_like(dout, memory_format=torch.contiguous_format)] + [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
 
 
-def _encoder_setup(ctx, inputs, output):
-    x, mask, params, dt, hid, L, H, attn_p, layer_p, seed = inputs
-    ctx.save_for_backward(output[1], *([mask] if mask is not None else []), *params)
-    ctx.cfg = (mask is not None, dt, hid, L, H, attn_p, layer_p, seed)
-    ctx.set_materialize_grads(False)
 
 
-def _encoder_bwd(ctx, dout, dsaved_unused):
-    has_mask, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
-    saved, *rest = ctx.saved_tensors
-    mask = rest.pop(0) if has_mask else None
-    if dout is None:
-        return (None, None, [None] * len(rest)) + (None,) * 7
-    res = torch.ops.hybrid.encoder_bwd(dout, mask, [p.detach() for p in rest], saved, dt, hid, L, H, attn_p, layer_p, seed)
-    return (res[0], None, list(res[1:])) + (None,) * 7
-
-
-encoder_op.register_autograd(_encoder_bwd, setup_context=_encoder_setup)
 
 
 def encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
@@ -509,7 +444,6 @@ def encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
 # ---------------------------------------------------------------------------------------------
 # standalone MultiheadAttention.forward(q, k, v, mask) -- src L67-89
 # ---------------------------------------------------------------------------------------------
-@torch.library.custom_op("hybrid::mha", mutates_args=())
 def mha_op(q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], dt: int, H: int, p_drop: float,
            seed: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     """params = Wq,bq,Wk,bk,Wv,bv,Wo,bo (fp32) -> (out, q, k, v, a, probs); all but `out` saved for backward."""
@@ -530,14 +464,12 @@ def mha_op(q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], par
     return out, q, k, v, a, probs
 
 
-@mha_op.register_fake
-def _(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed):
+def mha_fake(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed):
     B, S, D = q_in.shape
     e = lambda: q_in.new_empty((B, S, D), dtype=_TORCH_DTYPE[dt])
     return e(), e(), e(), e(), e(), q_in.new_empty((B * H, S, S), dtype=torch.float32)
 
 
-@torch.library.custom_op("hybrid::mha_bwd", mutates_args=())
 def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, q: Tensor, k: Tensor, v: Tensor, a: Tensor, probs: Tensor,
                params: Sequence[Tensor], dt: int, H: int, p_drop: float, seed: int) -> List[Tensor]:
     """-> [dq_in, dk_in, dv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo]"""
@@ -560,29 +492,12 @@ def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, q: Tensor
     return [dqi, dki, dvi] + grads
 
 
-@mha_bwd_op.register_fake
-def _(dout, q_in, k_in, v_in, q, k, v, a, probs, params, dt, H, p_drop, seed):
+def mha_bwd_fake(dout, q_in, k_in, v_in, q, k, v, a, probs, params, dt, H, p_drop, seed):
     return [torch.empty_like(q) for _ in range(3)] + [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
 
 
-def _mha_setup(ctx, inputs, output):
-    q_in, k_in, v_in, mask, params, dt, H, p_drop, seed = inputs
-    out, q, k, v, a, probs = output
-    ctx.save_for_backward(q_in, k_in, v_in, q, k, v, a, probs, *params)
-    ctx.cfg = (dt, H, p_drop, seed)
-    ctx.set_materialize_grads(False)
 
 
-def _mha_bwd(ctx, dout, *unused):
-    q_in, k_in, v_in, q, k, v, a, probs, *ps = ctx.saved_tensors
-    dt, H, p_drop, seed = ctx.cfg
-    if dout is None:
-        return (None, None, None, None, [None] * len(ps), None, None, None, None)
-    res = torch.ops.hybrid.mha_bwd(dout, q_in, k_in, v_in, q, k, v, a, probs, [p.detach() for p in ps], dt, H, p_drop, seed)
-    return (res[0], res[1], res[2], None, list(res[3:]), None, None, None, None)
-
-
-mha_op.register_autograd(_mha_bwd, setup_context=_mha_setup)
 
 
 def mha(q, k, v, mask, params, dt, H, p_drop, seed):
@@ -593,7 +508,6 @@ def mha(q, k, v, mask, params, dt, H, p_drop, seed):
 # ---------------------------------------------------------------------------------------------
 # head (mean over T + Linear) and cross-entropy
 # ---------------------------------------------------------------------------------------------
-@torch.library.custom_op("hybrid::head", mutates_args=())
 def head_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dt: int) -> Tensor:
     _require_cuda(x, weight)
     x = x.contiguous()
@@ -605,12 +519,10 @@ def head_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dt: int) -> Tenso
     return logits
 
 
-@head_op.register_fake
-def _(x, weight, bias, dt):
+def head_fake(x, weight, bias, dt):
     return x.new_empty((x.shape[0], weight.shape[0]), dtype=torch.float32)
 
 
-@torch.library.custom_op("hybrid::head_bwd", mutates_args=())
 def head_bwd_op(dlogits: Tensor, x: Tensor, weight: Tensor, has_bias: bool, dt: int) -> Tuple[Tensor, Tensor, Tensor]:
     _require_cuda(dlogits, x)
     B, S, D = x.shape
@@ -624,33 +536,19 @@ def head_bwd_op(dlogits: Tensor, x: Tensor, weight: Tensor, has_bias: bool, dt: 
     return dx, dw, db
 
 
-@head_bwd_op.register_fake
-def _(dlogits, x, weight, has_bias, dt):
+def head_bwd_fake(dlogits, x, weight, has_bias, dt):
     return (torch.empty_like(x), torch.empty_like(weight, memory_format=torch.contiguous_format),
             x.new_empty((weight.shape[0] if has_bias else 0,), dtype=torch.float32))
 
 
-def _head_setup(ctx, inputs, output):
-    x, weight, bias, dt = inputs
-    ctx.save_for_backward(x.contiguous(), weight)
-    ctx.cfg = (bias is not None, dt)
 
 
-def _head_bwd(ctx, dlogits):
-    x, weight = ctx.saved_tensors
-    has_bias, dt = ctx.cfg
-    dx, dw, db = torch.ops.hybrid.head_bwd(dlogits, x, weight.detach(), has_bias, dt)
-    return dx, dw, (db if has_bias else None), None
-
-
-head_op.register_autograd(_head_bwd, setup_context=_head_setup)
 
 
 def head(x, weight, bias, dt):
     return torch.ops.hybrid.head(x, weight, bias, dt)
 
 
-@torch.library.custom_op("hybrid::cross_entropy", mutates_args=())
 def cross_entropy_op(logits: Tensor, target: Tensor) -> Tensor:
     _require_cuda(logits, target)
     if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
@@ -663,12 +561,10 @@ def cross_entropy_op(logits: Tensor, target: Tensor) -> Tensor:
     return loss
 
 
-@cross_entropy_op.register_fake
-def _(logits, target):
+def cross_entropy_fake(logits, target):
     return logits.new_empty((), dtype=torch.float32)
 
 
-@torch.library.custom_op("hybrid::cross_entropy_bwd", mutates_args=())
 def cross_entropy_bwd_op(dloss: Tensor, logits: Tensor, target: Tensor) -> Tensor:
     _require_cuda(dloss, logits)
     logits = logits.contiguous().float()
@@ -680,21 +576,12 @@ def cross_entropy_bwd_op(dloss: Tensor, logits: Tensor, target: Tensor) -> Tenso
     return dlogits
 
 
-@cross_entropy_bwd_op.register_fake
-def _(dloss, logits, target):
+def cross_entropy_bwd_fake(dloss, logits, target):
     return logits.new_empty(logits.shape, dtype=torch.float32)
 
 
-def _ce_setup(ctx, inputs, output):
-    ctx.save_for_backward(*inputs)
 
 
-def _ce_bwd(ctx, dloss):
-    logits, target = ctx.saved_tensors
-    return torch.ops.hybrid.cross_entropy_bwd(dloss, logits, target), None
-
-
-cross_entropy_op.register_autograd(_ce_bwd, setup_context=_ce_setup)
 
 
 def cross_entropy(logits, target):
@@ -724,7 +611,6 @@ def _backbone_geometry(x, weights):
     return N, H, W, chans, dims
 
 
-@torch.library.custom_op("hybrid::backbone", mutates_args=())
 def backbone_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], betas: Sequence[Tensor], running_means: Sequence[Tensor],
                 running_vars: Sequence[Tensor], training: bool, momentum: float, eps: float, dt: int) -> List[Tensor]:
     """All conv stages of the backbone on NCHW fp32 frames x [N, C_in <= 4, H, W].
@@ -764,8 +650,7 @@ def backbone_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], 
     return res
 
 
-@backbone_op.register_fake
-def _(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt):
+def backbone_fake(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt):
     S = len(weights)
     N, H, W, chans, dims = _backbone_geometry(x, weights)
     tdt = _TORCH_DTYPE[dt]
@@ -794,7 +679,6 @@ def _backbone_unpack(res, S):
     return out
 
 
-@torch.library.custom_op("hybrid::backbone_bwd", mutates_args=())
 def backbone_bwd_op(dpooled: Tensor, x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], saved: Sequence[Tensor], training: bool,
                     dt: int) -> List[Tensor]:
     """saved: per stage (y_raw, stage input [placeholder for stage 0], scale_shift, mean_invstd, packed_bwd).
@@ -820,8 +704,7 @@ def backbone_bwd_op(dpooled: Tensor, x: Tensor, weights: Sequence[Tensor], gamma
     return grads
 
 
-@backbone_bwd_op.register_fake
-def _(dpooled, x, weights, gammas, saved, training, dt):
+def backbone_bwd_fake(dpooled, x, weights, gammas, saved, training, dt):
     res = []
     for w in weights:
         res += [torch.empty_like(w, memory_format=torch.contiguous_format), x.new_empty((w.shape[0],), dtype=torch.float32),
@@ -829,35 +712,8 @@ def _(dpooled, x, weights, gammas, saved, training, dt):
     return res
 
 
-def _backbone_setup(ctx, inputs, output):
-    x, weights, gammas, betas, rms, rvs, training, momentum, eps, dt = inputs
-    if ctx.needs_input_grad[0]:
-        raise RuntimeError("the first conv stage does not compute a gradient for its input (the clip tensor): pass clips with "
-                           "requires_grad=False (training data never needs one); a silent None would be wrong")
-    S = len(weights)
-    st = _backbone_unpack(output, S)
-    saved = []
-    for s in range(S):
-        y_raw, p, ss, mi, pk, ro = st[s]
-        saved += [y_raw, (st[s - 1][1] if s > 0 else y_raw), ss, mi, pk]
-    ctx.save_for_backward(x, *weights, *gammas, *saved)
-    ctx.cfg = (S, bool(training), dt)
-    ctx.set_materialize_grads(False)
 
 
-def _backbone_bwd(ctx, grads_out):
-    S, training, dt = ctx.cfg
-    t = ctx.saved_tensors
-    x, weights, gammas, saved = t[0], list(t[1:1 + S]), list(t[1 + S:1 + 2 * S]), list(t[1 + 2 * S:])
-    dpooled = grads_out[0]
-    none = [None] * S
-    if dpooled is None:
-        return (None, none, none, none, none, none, None, None, None, None)
-    g = torch.ops.hybrid.backbone_bwd(dpooled, x, [w.detach() for w in weights], [v.detach() for v in gammas], saved, training, dt)
-    return (None, [g[3 * s] for s in range(S)], [g[3 * s + 1] for s in range(S)], [g[3 * s + 2] for s in range(S)], none, none, None, None, None, None)
-
-
-backbone_op.register_autograd(_backbone_bwd, setup_context=_backbone_setup)
 
 
 def backbone(x, stages, training, dt):
@@ -872,7 +728,6 @@ def backbone(x, stages, training, dt):
     return res[0]
 
 
-@torch.library.custom_op("hybrid::temporal", mutates_args=())
 def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, head_b: Tensor, mask: Optional[Tensor],
                 B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """h [B*S, Hh, Ww, Cp] T (last pooled map) -> (logits [B, classes] fp32, feat, enc_saved, enc_out); the last three are saved for backward."""
@@ -896,8 +751,7 @@ def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequenc
     return logits, feat, saved, enc_out
 
 
-@temporal_op.register_fake
-def _(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
+def temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
     N, Hh, Ww, Cp = h.shape
     S, D = N // B, token_w.shape[0]
     tdt = _TORCH_DTYPE[dt]
@@ -905,7 +759,6 @@ def _(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, a
             h.new_empty((max(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), 256),), dtype=torch.uint8), h.new_empty((B, S, D), dtype=tdt))
 
 
-@torch.library.custom_op("hybrid::temporal_bwd", mutates_args=())
 def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, mask: Optional[Tensor], feat: Tensor,
                     saved: Tensor, enc_out: Tensor, Hh: int, Ww: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float,
                     seed: int) -> List[Tensor]:
@@ -932,37 +785,253 @@ def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tenso
     return [dh, dtw, dtb, dhw, dhb] + grads
 
 
-@temporal_bwd_op.register_fake
-def _(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed):
+def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed):
     N, Cp = feat.shape
     c = lambda t: torch.empty_like(t, memory_format=torch.contiguous_format)
     return [feat.new_empty((N, Hh, Ww, Cp)), c(token_w), feat.new_empty((token_w.shape[0],), dtype=torch.float32), c(head_w),
             feat.new_empty((head_w.shape[0],), dtype=torch.float32)] + [c(p) for p in enc_params]
 
 
-def _temporal_setup(ctx, inputs, output):
-    h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed = inputs
-    logits, feat, saved, enc_out = output
-    ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, *([mask] if mask is not None else []), *enc_params)
-    ctx.cfg = (mask is not None, h.shape[1], h.shape[2], dt, hid, L, H, attn_p, layer_p, seed)
-    ctx.set_materialize_grads(False)
 
 
-def _temporal_bwd(ctx, dlogits, *unused):
-    has_mask, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
-    token_w, head_w, feat, saved, enc_out, *rest = ctx.saved_tensors
-    mask = rest.pop(0) if has_mask else None
-    if dlogits is None:
-        return (None, None, None, [None] * len(rest), None, None) + (None,) * 9
-    g = torch.ops.hybrid.temporal_bwd(dlogits, token_w.detach(), [p.detach() for p in rest], head_w.detach(), mask, feat, saved, enc_out, Hh, Ww,
-                                      dt, hid, L, H, attn_p, layer_p, seed)
-    return (g[0], g[1], g[2], list(g[5:]), g[3], g[4]) + (None,) * 9
-
-
-temporal_op.register_autograd(_temporal_bwd, setup_context=_temporal_setup)
 
 
 def temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
     S = h.shape[0] // B
     return torch.ops.hybrid.temporal(h, token_w, token_b, list(enc_params), head_w, head_b, check_mask(mask, B, S, h.device), B, dt, hid, L, H,
                                      float(attn_p), float(layer_p), seed)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# Autograd-key kernels: one torch.autograd.Function per differentiable operator.  forward() re-enters the operator below the
+# Autograd key (the backend kernel above), saves what the backward operator needs, and marks the outputs that exist only to be
+# saved as non-differentiable; backward() is one call of the matching hybrid::*_bwd operator.
+# ---------------------------------------------------------------------------------------------
+_CLIP_GRAD_MSG = ("the first conv stage does not compute a gradient for its input (the clip tensor): pass clips with "
+                  "requires_grad=False (training data never needs one); a silent None would be wrong")
+
+
+class _NchwToNhwcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt, cp):
+        ctx.cfg = (dt, x.shape[1])
+        with _below_autograd():
+            return torch.ops.hybrid.nchw_to_nhwc(x, dt, cp)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.ops.hybrid.nhwc_to_nchw(g, *ctx.cfg), None, None
+
+
+class _NhwcToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt, C):
+        ctx.cfg = (dt, x.shape[3])
+        with _below_autograd():
+            return torch.ops.hybrid.nhwc_to_nchw(x, dt, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.ops.hybrid.nchw_to_nhwc(g, *ctx.cfg), None, None
+
+
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt, to_t):
+        ctx.cfg = (dt, not to_t)
+        with _below_autograd():
+            return torch.ops.hybrid.cast(x, dt, to_t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.ops.hybrid.cast(g, *ctx.cfg), None, None
+
+
+class _ConvStageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, rm, rv, training, momentum, eps, dt, first):
+        if first and ctx.needs_input_grad[0]:
+            raise RuntimeError(_CLIP_GRAD_MSG)
+        with _below_autograd():
+            out = torch.ops.hybrid.convstage(x, weight, gamma, beta, rm, rv, training, momentum, eps, dt, first)
+        ctx.save_for_backward(x, out[1], weight, gamma, out[2], out[3], out[4])
+        ctx.cfg = (training, dt, first)
+        ctx.mark_non_differentiable(*out[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dpooled, *unused):
+        x, y_raw, weight, gamma, ss, mi, pk = ctx.saved_tensors
+        training, dt, first = ctx.cfg
+        dx, dw, dgamma, dbeta = torch.ops.hybrid.convstage_bwd(dpooled, x, y_raw, weight, gamma, ss, mi, pk, training, dt, first)
+        return (None if first else dx, dw, dgamma, dbeta) + (None,) * 7
+
+
+class _TokenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dt):
+        with _below_autograd():
+            tok, feat = torch.ops.hybrid.token(x, weight, bias, dt)
+        ctx.save_for_backward(feat, weight)
+        ctx.cfg = (x.shape[1], x.shape[2], bias is not None, dt)
+        ctx.mark_non_differentiable(feat)
+        return tok, feat
+
+    @staticmethod
+    def backward(ctx, dtok, unused):
+        feat, weight = ctx.saved_tensors
+        Hh, Ww, has_bias, dt = ctx.cfg
+        dx, dw, db = torch.ops.hybrid.token_bwd(dtok, feat, weight, Hh, Ww, has_bias, dt)
+        return dx, dw, (db if has_bias else None), None
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, dt, hid, L, H, attn_p, layer_p, seed, *params):
+        with _below_autograd():
+            out, saved = torch.ops.hybrid.encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed)
+        ctx.save_for_backward(saved, *params) if mask is None else ctx.save_for_backward(saved, mask, *params)
+        ctx.cfg = (mask is not None, dt, hid, L, H, attn_p, layer_p, seed)
+        ctx.mark_non_differentiable(saved)
+        return out, saved
+
+    @staticmethod
+    def backward(ctx, dout, unused):
+        has_mask, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
+        saved, *rest = ctx.saved_tensors
+        mask = rest.pop(0) if has_mask else None
+        res = torch.ops.hybrid.encoder_bwd(dout, mask, rest, saved, dt, hid, L, H, attn_p, layer_p, seed)
+        return (res[0],) + (None,) * 8 + tuple(res[1:])
+
+
+class _MhaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_in, k_in, v_in, mask, dt, H, p_drop, seed, *params):
+        with _below_autograd():
+            out = torch.ops.hybrid.mha(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed)
+        ctx.save_for_backward(q_in, k_in, v_in, *out[1:], *params)
+        ctx.cfg = (dt, H, p_drop, seed)
+        ctx.mark_non_differentiable(*out[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        q_in, k_in, v_in, q, k, v, a, probs, *ps = ctx.saved_tensors
+        res = torch.ops.hybrid.mha_bwd(dout, q_in, k_in, v_in, q, k, v, a, probs, ps, *ctx.cfg)
+        return (res[0], res[1], res[2]) + (None,) * 5 + tuple(res[3:])
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dt):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (bias is not None, dt)
+        with _below_autograd():
+            return torch.ops.hybrid.head(x, weight, bias, dt)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, weight = ctx.saved_tensors
+        has_bias, dt = ctx.cfg
+        dx, dw, db = torch.ops.hybrid.head_bwd(dlogits, x.contiguous(), weight, has_bias, dt)
+        return dx, dw, (db if has_bias else None), None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        ctx.save_for_backward(logits, target)
+        with _below_autograd():
+            return torch.ops.hybrid.cross_entropy(logits, target)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target = ctx.saved_tensors
+        return torch.ops.hybrid.cross_entropy_bwd(dloss, logits, target), None
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, S, training, momentum, eps, dt, *tensors):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError(_CLIP_GRAD_MSG)
+        weights, gammas, betas, rms, rvs = (tensors[i * S:(i + 1) * S] for i in range(5))
+        with _below_autograd():
+            res = torch.ops.hybrid.backbone(x, weights, gammas, betas, rms, rvs, training, momentum, eps, dt)
+        st = _backbone_unpack(res, S)
+        saved = []
+        for s in range(S):
+            saved += [st[s][0], (st[s - 1][1] if s > 0 else st[s][0]), st[s][2], st[s][3], st[s][4]]
+        ctx.save_for_backward(x, *weights, *gammas, *saved)
+        ctx.cfg = (S, training, dt)
+        ctx.mark_non_differentiable(*res[1:])
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, dpooled, *unused):
+        S, training, dt = ctx.cfg
+        t = ctx.saved_tensors
+        g = torch.ops.hybrid.backbone_bwd(dpooled, t[0], t[1:1 + S], t[1 + S:1 + 2 * S], t[1 + 2 * S:], training, dt)
+        return (None,) * 6 + tuple(g[0::3]) + tuple(g[1::3]) + tuple(g[2::3]) + (None,) * (2 * S)
+
+
+class _TemporalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, token_w, token_b, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, *enc_params):
+        with _below_autograd():
+            logits, feat, saved, enc_out = torch.ops.hybrid.temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H,
+                                                                      attn_p, layer_p, seed)
+        if mask is None:
+            ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, *enc_params)
+        else:
+            ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, mask, *enc_params)
+        ctx.cfg = (mask is not None, h.shape[1], h.shape[2], dt, hid, L, H, attn_p, layer_p, seed)
+        ctx.mark_non_differentiable(feat, saved, enc_out)
+        return logits, feat, saved, enc_out
+
+    @staticmethod
+    def backward(ctx, dlogits, *unused):
+        has_mask, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
+        token_w, head_w, feat, saved, enc_out, *rest = ctx.saved_tensors
+        mask = rest.pop(0) if has_mask else None
+        g = torch.ops.hybrid.temporal_bwd(dlogits, token_w, rest, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed)
+        return (g[0], g[1], g[2], g[3], g[4]) + (None,) * 9 + tuple(g[5:])
+
+
+_define("nchw_to_nhwc", "(Tensor x, int dt, int cp) -> Tensor", nchw_to_nhwc_op, nchw_to_nhwc_fake, _NchwToNhwcFn.apply)
+_define("nhwc_to_nchw", "(Tensor x, int dt, int C) -> Tensor", nhwc_to_nchw_op, nhwc_to_nchw_fake, _NhwcToNchwFn.apply)
+_define("cast", "(Tensor x, int dt, bool to_t) -> Tensor", cast_op, cast_fake, _CastFn.apply)
+_define("convstage", "(Tensor x, Tensor weight, Tensor gamma, Tensor beta, Tensor? running_mean, Tensor? running_var, bool training, float momentum, "
+        "float eps, int dt, bool first) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", convstage_op, convstage_fake, _ConvStageFn.apply)
+_define("convstage_bwd", "(Tensor dpooled, Tensor x, Tensor y_raw, Tensor weight, Tensor gamma, Tensor scale_shift, Tensor mean_invstd, "
+        "Tensor packed_bwd, bool training, int dt, bool first) -> (Tensor, Tensor, Tensor, Tensor)", convstage_bwd_op, convstage_bwd_fake)
+_define("token", "(Tensor x, Tensor weight, Tensor? bias, int dt) -> (Tensor, Tensor)", token_op, token_fake, _TokenFn.apply)
+_define("token_bwd", "(Tensor dtok, Tensor feat, Tensor weight, int Hh, int Ww, bool has_bias, int dt) -> (Tensor, Tensor, Tensor)", token_bwd_op,
+        token_bwd_fake)
+_define("encoder", "(Tensor x, Tensor? mask, Tensor[] params, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed) -> (Tensor, Tensor)",
+        encoder_op, encoder_fake,
+        lambda x, mask, params, dt, hid, L, H, attn_p, layer_p, seed: _EncoderFn.apply(x, mask, dt, hid, L, H, attn_p, layer_p, seed, *params))
+_define("encoder_bwd", "(Tensor dout, Tensor? mask, Tensor[] params, Tensor saved, int dt, int hid, int L, int H, float attn_p, float layer_p, "
+        "int seed) -> Tensor[]", encoder_bwd_op, encoder_bwd_fake)
+_define("mha", "(Tensor q_in, Tensor k_in, Tensor v_in, Tensor? mask, Tensor[] params, int dt, int H, float p_drop, int seed) -> "
+        "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", mha_op, mha_fake,
+        lambda q, k, v, mask, params, dt, H, p_drop, seed: _MhaFn.apply(q, k, v, mask, dt, H, p_drop, seed, *params))
+_define("mha_bwd", "(Tensor dout, Tensor q_in, Tensor k_in, Tensor v_in, Tensor q, Tensor k, Tensor v, Tensor a, Tensor probs, Tensor[] params, "
+        "int dt, int H, float p_drop, int seed) -> Tensor[]", mha_bwd_op, mha_bwd_fake)
+_define("head", "(Tensor x, Tensor weight, Tensor? bias, int dt) -> Tensor", head_op, head_fake, _HeadFn.apply)
+_define("head_bwd", "(Tensor dlogits, Tensor x, Tensor weight, bool has_bias, int dt) -> (Tensor, Tensor, Tensor)", head_bwd_op, head_bwd_fake)
+_define("cross_entropy", "(Tensor logits, Tensor target) -> Tensor", cross_entropy_op, cross_entropy_fake, _CrossEntropyFn.apply)
+_define("cross_entropy_bwd", "(Tensor dloss, Tensor logits, Tensor target) -> Tensor", cross_entropy_bwd_op, cross_entropy_bwd_fake)
+_define("backbone", "(Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] betas, Tensor[] running_means, Tensor[] running_vars, bool training, "
+        "float momentum, float eps, int dt) -> Tensor[]", backbone_op, backbone_fake,
+        lambda x, ws, gs, bs, rms, rvs, training, momentum, eps, dt: list(_BackboneFn.apply(x, len(ws), training, momentum, eps, dt, *ws, *gs, *bs,
+                                                                                          *rms, *rvs)))
+_define("backbone_bwd", "(Tensor dpooled, Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] saved, bool training, int dt) -> Tensor[]",
+        backbone_bwd_op, backbone_bwd_fake)
+_define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_params, Tensor head_w, Tensor head_b, Tensor? mask, int B, int dt, "
+        "int hid, int L, int H, float attn_p, float layer_p, int seed) -> (Tensor, Tensor, Tensor, Tensor)", temporal_op, temporal_fake,
+        lambda h, tw, tb, ps, hw, hb, mask, B, dt, hid, L, H, attn_p, layer_p, seed: _TemporalFn.apply(h, tw, tb, hw, hb, mask, B, dt, hid, L, H,
+                                                                                                     attn_p, layer_p, seed, *ps))
+_define("temporal_bwd", "(Tensor dlogits, Tensor token_w, Tensor[] enc_params, Tensor head_w, Tensor? mask, Tensor feat, Tensor saved, "
+        "Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed) -> Tensor[]", temporal_bwd_op,
+        temporal_bwd_fake)
