@@ -187,12 +187,14 @@ int hyb_linear_bwd(int dtype, const void* x, int ldx, const float* W, const void
  * b*H+h).  scores = q k^T / sqrt(D) (D = d_model, quirk Q1); mask: NULL or fp32 [B,S,S],
  * row b*H+h uses mask[(b*H+h) % B] (quirk Q4: mask.repeat(H,1,1)); masked_fill(mask==0,-1e9);
  * softmax; dropout(p_drop) on the weights (src L58, counter-based RNG keyed by seed);
- * out = weights v.  probs: fp32 [B*H,S,S] softmax output BEFORE dropout (saved for backward).
- * Limits: S <= 64, D/H in {16,32,64,96,128} (multiple of 16, <= 128). */
+ * out = weights v.  stats: fp32 [B*H,S,2] = (row max, row sum of exp) of the scaled, masked scores -- all the backward needs to
+ * recompute the probabilities (the fp32 probability matrix of the first generation is gone); pass the SAME mask, p_drop and seed
+ * to the backward call.
+ * Limits: S <= 64, D/H a multiple of 8, <= 128. */
 int hyb_attention_fwd(int dtype, const void* q, const void* k, const void* v, const float* mask,
-                      void* out, float* probs, int B, int S, int D, int H, float p_drop,
+                      void* out, float* stats, int B, int S, int D, int H, float p_drop,
                       unsigned long long seed, void* stream);
-int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* probs,
+int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* mask, const float* stats,
                       const void* dout, void* dq, void* dk, void* dv, int B, int S, int D, int H,
                       float p_drop, unsigned long long seed, void* stream);
 

@@ -233,7 +233,9 @@ def test_attention_scores_exact_with_uniform_values(mode):
         vrow = torch.randint(-8, 9, (B, 1, D), generator=g).float()
         v = vrow.expand(B, S, D).contiguous().cuda().to(tdt)
         out = torch.empty(B, S, D, dtype=tdt, device="cuda")
-        probs = torch.empty(B * H, S, S, device="cuda")
-        L().call("hyb_attention_fwd", code, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), probs.data_ptr(), B, S, D, H, 0.0, 0, st())
-        assert torch.allclose(probs.sum(-1), torch.ones(B * H, S, device="cuda"), atol=1e-5)
+        stats = torch.empty(B * H, S, 2, device="cuda")                 # (row max, row sum of exp) per query
+        L().call("hyb_attention_fwd", code, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), stats.data_ptr(), B, S, D, H, 0.0, 0, st())
+        sc = torch.einsum("bhqd,bhkd->bhqk", q.float().view(B, S, H, D // H).transpose(1, 2), k.float().view(B, S, H, D // H).transpose(1, 2)) / D ** 0.5
+        assert torch.allclose(stats[..., 0], sc.amax(-1).reshape(B * H, S), atol=1e-4, rtol=1e-4)
+        assert torch.allclose(stats[..., 1], torch.exp(sc - sc.amax(-1, keepdim=True)).sum(-1).reshape(B * H, S), rtol=1e-3)
         assert torch.allclose(out.float().cpu(), vrow.expand(B, S, D), atol=0.07 if mode == "bf16" else 1e-4)

@@ -107,7 +107,7 @@ def test_opcheck_encoder_and_mha(dt, use_mask):
     q, k, v = (torch.randn(B, S, D, device="cuda").to(tdt).requires_grad_(True) for _ in range(3))
     _opcheck(torch.ops.hybrid.mha.default, (q, k, v, mask, mp, dt, H, 0.1, 99))
     r = torch.ops.hybrid.mha(q, k, v, mask, mp, dt, H, 0.1, 99)
-    _opcheck(torch.ops.hybrid.mha_bwd.default, (torch.randn_like(r[0]), q.detach(), k.detach(), v.detach(), r[1].detach(), r[2].detach(),
+    _opcheck(torch.ops.hybrid.mha_bwd.default, (torch.randn_like(r[0]), q.detach(), k.detach(), v.detach(), mask, r[1].detach(), r[2].detach(),
                                                 r[3].detach(), r[4].detach(), r[5].detach(), [p.detach() for p in mp], dt, H, 0.1, 99))
 
 

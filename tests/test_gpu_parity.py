@@ -181,7 +181,9 @@ def test_golden_g2_reference_two_stage_on_hip():
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,S,D,H,use_mask", [(2, 16, 64, 4, False), (1, 1, 16, 2, False), (3, 5, 24, 3, True), (2, 33, 128, 2, True),
-                                              (8, 16, 512, 8, False), (2, 64, 768, 8, False), (2, 64, 256, 2, True)])
+                                              (8, 16, 512, 8, False), (2, 64, 768, 8, False), (2, 64, 256, 2, True),
+                                              (683, 7, 24, 3, False), (300, 16, 64, 8, True),      # >= 2048 problems: four per workgroup (+ a ragged last one)
+                                              (3, 40, 96, 2, True), (2, 17, 32, 4, False)])          # 3 and 2 tiles with ragged tails
 def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
     ftol, gtol = TOL[mode]
     torch.manual_seed(2)
@@ -276,7 +278,7 @@ def test_attention_dropout_statistics_and_backward_consistency():
     # directional derivative of sum(out*r) wrt v matches dv from the backward kernel with the same seed
     r = torch.randn_like(q)
     dq, dk, dv = (torch.empty_like(q) for _ in range(3))
-    lib.call("hyb_attention_bwd", HYB_F32, q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), r.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, S, D, H, 0.5, 7, st)
+    lib.call("hyb_attention_bwd", HYB_F32, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, probs.data_ptr(), r.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, S, D, H, 0.5, 7, st)
     dirv = torch.randn_like(v)
     eps = 1e-2
     lib.call("hyb_attention_fwd", HYB_F32, q.data_ptr(), k.data_ptr(), (v + eps * dirv).data_ptr(), None, out2.data_ptr(), probs.data_ptr(), B, S, D, H, 0.5, 7, st)

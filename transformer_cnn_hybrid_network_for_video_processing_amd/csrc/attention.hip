@@ -1,360 +1,530 @@
 // Temporal attention core of MultiheadAttention.attention (TransformerEncoder.pyc src L49-62) with the head
 // split/merge of __reshape_to_batches__/__reshape_from_batches__ (src L22-45) done as index math.
 //
-// One workgroup (4 waves) per (batch, head) problem; S <= 64 tokens, so Q, K, V, the score matrix and P all
-// live in LDS.  QK^T, P.V and the five backward products run on the matrix cores (16x16 tiles, k32 steps);
-// the softmax row reduce is a 16-lane wave shuffle.  Reference quirks kept: scale 1/sqrt(d_model) (Q1),
-// mask row b*H+h reads mask[(b*H+h) % B] (Q4), masked_fill(-1e9), dropout on the weights (src L58).
+// Second generation (round 2).  One wave owns one 16-query tile of one (clip, head) problem and keeps the whole softmax in
+// registers; a workgroup is ceil(S/16) such waves (ONE wave at T = 16).  Nothing is padded to 32 tokens, no score or
+// probability ever touches LDS or HBM, and there is no transposing scatter:
+//
+//   forward   S^T = K Q^T  (16x16x32 MFMA, both fragments loaded straight from HBM/L2, 16 B per lane).  The accumulator of the
+//             swapped product holds  S^T[key = 4g + r][query = p]  (p = lane & 15, g = lane >> 4): a query's keys sit in 4
+//             registers x 4 lanes, so the row max / sum are 3 register ops + 2 cross-lane steps, and the SAME registers,
+//             converted to T, are the B operand (k = key) of the 16x16x16 MFMA computing  O^T = V^T P^T  -- the A operand
+//             V^T[d][key] is a transposed LDS read (ds_read_b64_tr_b16) of the row-major V image.  O^T's accumulator holds 4
+//             consecutive features of one query: an 8-byte store.
+//             Saved for backward: the row max and row sum (2 floats per query) instead of the fp32 probabilities.
+//   backward  phase A (wave = query tile): P^T and dP^T = V dO^T recomputed in the swapped orientation -> delta, dS^T ->
+//             dQ^T = K^T dS^T (K^T by transposed LDS reads).  phase B (wave = KEY tile, all query tiles): P and dP = dO V^T in
+//             the normal orientation (accumulator = [query = 4g + r][key = p]) are the B operands (k = query) of
+//             dK^T = Q^T dS and dV^T = dO^T (P * dropout).  Each wave ends with complete dK / dV tiles: no cross-wave reduction.
+//
+// LDS images are row-major with a row stride that is an odd multiple of 32 bytes, which makes every transposed read
+// conflict-free (8 rows x 32 B of a 32-lane half tile the 64 banks exactly).
+// Reference quirks kept: scale 1/sqrt(d_model) (Q1), mask row b*H+h reads mask[(b*H+h) % B] (Q4), masked_fill(-1e9),
+// dropout on the weights (src L58).  fp32 mode runs the same structure on v_mfma_f32_16x16x4_f32.
+#include <stdlib.h>
 #include "hyb_common.h"
 
 namespace {
 
 struct AttnDims {
     int B, S, D, H, dh;
-    int SK;      // S rounded up to 32 (token dimension padding)
-    int dhp;     // dh rounded up to 32 (feature padding for the k32 step)
+    int nt;      // 16-token tiles per sequence = waves per workgroup
+    int DT;      // 16-feature tiles per head
+    int ldi;     // LDS image row stride in elements
     int ld_qkv;  // token row stride (elements) of q, k, v and dq, dk, dv (D, or 3D when they are packed as [M][3D])
     int ld_o;    // token row stride of out / dout
+    int ppw;     // problems per workgroup: > 1 only for single-tile sequences (S <= 16), where every wave takes its own (clip, head)
 };
 
-// dst[s][c] = src[(b*S + s)*D + h*dh + c], zero padded to [SK][dhp]; row stride ld
-template <typename T>
-__device__ __forceinline__ void stage_rows(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid, int gld) {
-    const int segs = d.dhp >> 3;
-    for (int u = tid; u < d.SK * segs; u += 256) {
-        const int s = u / segs, c = (u - s * segs) * 8;
-        Vec8<T> v;
-        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * gld + h * d.dh + c);
-        else v.zero();
-        v.store(dst + s * ld + c);
-    }
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_a;
+
+// ---- a 16-deep K step (the k = token contractions) -----------------------------------------------------------------
+// One lane's share: 4 consecutive K elements of one row (A) / column (B); lane l holds row/col (l & 15), K = 4*(l >> 4) + j.
+//   bf16: the operand of v_mfma_f32_16x16x16_bf16.   fp32: four v_mfma_f32_16x16x4_f32, MFMA j contracting K = {4g + j}.
+// An accumulator tile (rows 4g + r, column p) is therefore directly the B operand whose K index is the accumulator's row.
+template <typename T> struct Frag16;
+template <> struct Frag16<bf16> { bf16x4 v; };
+template <> struct Frag16<float> { float v[4]; };
+__device__ __forceinline__ f32x4 mma16(const Frag16<bf16>& a, const Frag16<bf16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a.v), __builtin_bit_cast(s16x4, b.v), c, 0, 0, 0);
 }
-// dst[c][s] = src[(b*S + s)*D + h*dh + c], zero padded to [dhp][SK]; row stride ld
-template <typename T>
-__device__ __forceinline__ void stage_cols(T* dst, int ld, const T* src, const AttnDims& d, int b, int h, int tid, int gld) {
-    const int segs = d.dhp >> 3;
-    for (int u = tid; u < d.SK * segs; u += 256) {
-        const int s = u / segs, c = (u - s * segs) * 8;
-        Vec8<T> v;
-        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * gld + h * d.dh + c);
-        else v.zero();
+__device__ __forceinline__ f32x4 mma16(const Frag16<float>& a, const Frag16<float>& b, f32x4 c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[(c + j) * ld + s] = from_f32<T>(v.get(j));
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ void acc_to_frag(Frag16<bf16>& f, const float (&x)[4]) {
+    f.v[0] = (bf16)x[0]; f.v[1] = (bf16)x[1]; f.v[2] = (bf16)x[2]; f.v[3] = (bf16)x[3];
+}
+__device__ __forceinline__ void acc_to_frag(Frag16<float>& f, const float (&x)[4]) {
+    f.v[0] = x[0]; f.v[1] = x[1]; f.v[2] = x[2]; f.v[3] = x[3];
+}
+// A operand  M^T[col c0 + p][rows r0 + 4g + j]  of a row-major LDS image img[row][ld]: 4 rows x 16 columns per 16-lane group,
+// delivered column-major by the hardware transpose read (every lane active, every address inside the image).
+__device__ __forceinline__ void tr_read(Frag16<bf16>& f, const bf16* img, int ld, int r0, int c0, int lane) {
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    f.v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(img + (r0 + 4 * g + qq) * ld + c0 + 4 * pp));
+}
+__device__ __forceinline__ void tr_read(Frag16<float>& f, const float* img, int ld, int r0, int c0, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.v[j] = img[(r0 + 4 * g + j) * ld + c0 + p];
+}
+
+// rows [16*nt][ld] of an LDS image <- src[(b*S + s)*gld + h*dh + c]; rows >= S and columns >= dh are zero
+template <typename T>
+__device__ __forceinline__ void stage_image(T* img, const T* __restrict__ src, const AttnDims& d, int b, int h, int gld, int tid, int nthreads) {
+    const int segs = d.DT * 2;                       // 8-element chunks per row
+    for (int u = tid; u < d.nt * 16 * segs; u += nthreads) {
+        const int s = u / segs, c = (u - s * segs) * 8;
+        Vec8<T> v;
+        if (s < d.S && c < d.dh) v.load(src + ((long long)(b * d.S + s)) * gld + h * d.dh + c);
+        else v.zero();
+        v.store(img + s * d.ldi + c);
     }
 }
 
-// one 16x16 output tile: rows from Arows (row-major, k contiguous), cols from Brows
+// k32 fragment of token row `tok` (clamped; rows >= S are masked later), features f0 .. f0+7; zero past the head width
 template <typename T>
-__device__ __forceinline__ f32x4 mm_tile(const T* Arows, int lda, const T* Brows, int ldb, int kdim, int lane) {
-    const int p = lane & 15, q = lane >> 4;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < kdim; k0 += 32) {
-        Frag<T> a, b;
-        frag_load(a, Arows + p * lda + k0 + 8 * q);
-        frag_load(b, Brows + p * ldb + k0 + 8 * q);
-        acc = mma32(a, b, acc);
-    }
-    return acc;
+__device__ __forceinline__ void row_frag(Frag<T>& f, const T* __restrict__ base, long long gld, int tok, int S, int f0, int dh) {
+    if (f0 < dh) frag_load(f, base + (long long)(tok < S ? tok : S - 1) * gld + f0);
+    else frag_zero(f);
+}
+
+__device__ __forceinline__ float quad_lane_max(float v) {        // over the 4 lanes p, p+16, p+32, p+48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_lane_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                            const float* __restrict__ mask, T* __restrict__ out, float* __restrict__ probs,
-                                                            AttnDims d, float scale, float p_drop, unsigned long long seed) {
+__device__ __forceinline__ void store4(T* dst, const f32x4& o) {
+    if (sizeof(T) == 2) {
+        bf16x4 w; w[0] = (bf16)o[0]; w[1] = (bf16)o[1]; w[2] = (bf16)o[2]; w[3] = (bf16)o[3];
+        *reinterpret_cast<bf16x4*>(dst) = w;
+    } else {
+        *reinterpret_cast<f32x4*>(dst) = o;
+    }
+}
+
+constexpr int MAXT = 4;       // S <= 64
+constexpr int MAXDT = 8;      // head width <= 128
+
+// SINGLE: S <= 16 (one token tile): the tile loops collapse at compile time and the kernel fits 128 VGPRs (4 waves per SIMD)
+template <typename T, bool SINGLE>
+__global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
+                                     T* __restrict__ out, float* __restrict__ stats, AttnDims d, float scale, float p_drop, unsigned long long seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int ldq = d.dhp + 8, lds_ = d.SK + 8, ldsc = d.SK + 4;
-    T* Ql = reinterpret_cast<T*>(smem_raw);
-    T* Kl = Ql + d.SK * ldq;
-    T* Vt = Kl + d.SK * ldq;            // [dhp][SK+8]
-    T* Pl = Vt + d.dhp * lds_;          // [SK][SK+8]
-    float* Sc = reinterpret_cast<float*>(Pl + d.SK * lds_);   // [SK][SK+4]
-
+    constexpr int NTC = SINGLE ? 1 : MAXT;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pidx = blockIdx.x, b = pidx / d.H, h = pidx % d.H;
-    const int p = lane & 15, qq = lane >> 4;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool multi = d.ppw > 1;                              // S <= 16: one wave = one whole problem, several problems per workgroup
+    const int slot = multi ? wave_all : 0, wave = multi ? 0 : wave_all;
+    const int nw = multi ? 1 : (int)(blockDim.x >> 6);        // waves per problem: each takes query tiles wave, wave + nw, ...
+    int pidx = blockIdx.x * d.ppw + slot;
+    const bool valid = pidx < d.B * d.H;
+    if (!valid) pidx = d.B * d.H - 1;                          // keep every wave alive for the barrier and the cross-lane reads; no stores
+    const int b = pidx / d.H, h = pidx - b * d.H;
+    T* Vimg = reinterpret_cast<T*>(smem_raw) + (size_t)slot * d.nt * 16 * d.ldi;      // [16*nt][ldi]
+    const int p = lane & 15, g = lane >> 4;
+    const T* qb = q + (long long)b * d.S * d.ld_qkv + h * d.dh;
+    const T* kb = k + (long long)b * d.S * d.ld_qkv + h * d.dh;
 
-    stage_rows(Ql, ldq, q, d, b, h, tid, d.ld_qkv);
-    stage_rows(Kl, ldq, k, d, b, h, tid, d.ld_qkv);
-    stage_cols(Vt, lds_, v, d, b, h, tid, d.ld_qkv);
-    __syncthreads();
-
-    const int nt = d.SK >> 4;
-    const float* mrow = mask ? mask + (long long)(pidx % d.B) * d.S * d.S : nullptr;
-    for (int t = wave; t < nt * nt; t += 4) {
-        const int ti = t / nt, tj = t % nt;
-        const f32x4 acc = mm_tile(Ql + ti * 16 * ldq, ldq, Kl + tj * 16 * ldq, ldq, d.dhp, lane);
-        const int col = tj * 16 + p;
+    stage_image(Vimg, v, d, b, h, d.ld_qkv, multi ? lane : tid, multi ? 64 : (int)blockDim.x);
+    __syncthreads();                                           // V image complete
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (int qt = wave; qt < d.nt; qt += nw) {
+    // S^T tiles: rows = keys of tile kt, columns = this tile's 16 queries
+    const int query = qt * 16 + p;
+    f32x4 sT[NTC];
+    const int ks = (d.dh + 31) >> 5;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = ti * 16 + 4 * qq + r;
-            float sv = acc[r] * scale;
-            if (mrow && row < d.S && col < d.S && mrow[row * d.S + col] == 0.f) sv = -1e9f;
-            if (col >= d.S) sv = -INFINITY;
-            Sc[row * ldsc + col] = sv;
+    for (int kt = 0; kt < NTC; ++kt) {
+        sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < d.nt) {
+            for (int s = 0; s < ks; ++s) {
+                Frag<T> a, bq;
+                row_frag(a, kb, d.ld_qkv, kt * 16 + p, d.S, s * 32 + 8 * g, d.dh);
+                row_frag(bq, qb, d.ld_qkv, query, d.S, s * 32 + 8 * g, d.dh);
+                sT[kt] = mma32(a, bq, sT[kt]);
+            }
         }
     }
-    __syncthreads();
-
-    // softmax: one row per 16-lane group
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    for (int row = wave * 4 + qq; row < d.SK; row += 16) {
-        float vals[4];
-        float mx = -INFINITY;
+    // scale, mask, softmax over the keys of each query (register + 4-lane reduction)
+    const float* mrow = mask ? mask + ((long long)(pidx % d.B) * d.S + (query < d.S ? query : 0)) * d.S : nullptr;
+    float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = p + 16 * c;
-            vals[c] = col < d.SK ? Sc[row * ldsc + col] : -INFINITY;
-            mx = fmaxf(mx, vals[c]);
+    for (int kt = 0; kt < NTC; ++kt)
+        if (kt < d.nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                float sv = sT[kt][r] * scale;
+                if (key >= d.S) sv = -INFINITY;
+                else if (mrow && mrow[key] == 0.f) sv = -1e9f;
+                sT[kt][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
         }
-        mx = group16_max(mx);
-        float sum = 0.f;
+    mx = quad_lane_max(mx);
+    float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { vals[c] = __expf(vals[c] - mx); sum += vals[c]; }
-        sum = group16_sum(sum);
-        const float inv = 1.f / sum;
+    for (int kt = 0; kt < NTC; ++kt)
+        if (kt < d.nt) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = p + 16 * c;
-            if (col >= d.SK) continue;
-            float pv = vals[c] * inv;
-            if (row < d.S && col < d.S) {
-                probs[((long long)pidx * d.S + row) * d.S + col] = pv;
-                if (p_drop > 0.f) pv *= dropout_mult(seed, ((unsigned long long)pidx * d.S + row) * d.S + col, p_drop, inv_keep);
+            for (int r = 0; r < 4; ++r) { const float e = __expf(sT[kt][r] - mx); sT[kt][r] = e; sum += e; }
+        }
+    sum = quad_lane_sum(sum);
+    const float inv = 1.f / sum;
+    if (g == 0 && query < d.S && valid) {
+        float* st = stats + ((long long)pidx * d.S + query) * 2;
+        st[0] = mx; st[1] = sum;
+    }
+    Frag16<T> P[NTC];
+#pragma unroll
+    for (int kt = 0; kt < NTC; ++kt)
+        if (kt < d.nt) {
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                float x = sT[kt][r] * inv;
+                if (p_drop > 0.f && key < d.S && query < d.S)
+                    x *= dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
+                pv[r] = x;
+            }
+            acc_to_frag(P[kt], pv);
+        }
+    // O^T = V^T P^T, one 16-feature tile at a time; lane (p, g) ends with O[query p][16 dt + 4g .. + 3]
+#pragma unroll
+    for (int dt = 0; dt < MAXDT; ++dt) {
+        if (dt < d.DT) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NTC; ++kt)
+                if (kt < d.nt) {
+                    Frag16<T> a;
+                    tr_read(a, Vimg, d.ldi, kt * 16, dt * 16, lane);
+                    o = mma16(a, P[kt], o);
+                }
+            const int f0 = dt * 16 + 4 * g;
+            if (valid && query < d.S && f0 < d.dh) store4(out + ((long long)(b * d.S + query)) * d.ld_o + h * d.dh + f0, o);
+        }
+    }
+  }
+}
+
+template <typename T, bool SINGLE>
+__global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
+                                     const float* __restrict__ stats, const T* __restrict__ dout, T* __restrict__ dq, T* __restrict__ dk,
+                                     T* __restrict__ dv, AttnDims d, float scale, float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NTC = SINGLE ? 1 : MAXT;
+    const int rows = d.nt * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool multi = d.ppw > 1;
+    const int slot = multi ? wave_all : 0, wave = multi ? 0 : wave_all;
+    const int nw = multi ? 1 : (int)(blockDim.x >> 6);
+    int pidx = blockIdx.x * d.ppw + slot;
+    const bool valid = pidx < d.B * d.H;
+    if (!valid) pidx = d.B * d.H - 1;
+    const int b = pidx / d.H, h = pidx - b * d.H;
+    T* Kimg = reinterpret_cast<T*>(smem_raw + (size_t)slot * ((size_t)3 * rows * d.ldi * sizeof(T) + (size_t)rows * sizeof(float)));
+    T* Qimg = Kimg + rows * d.ldi;
+    T* Gimg = Qimg + rows * d.ldi;                             // dO
+    float* delta = reinterpret_cast<float*>(Gimg + rows * d.ldi);   // [rows]
+    const int p = lane & 15, g = lane >> 4;
+    const long long boff = (long long)b * d.S * d.ld_qkv + h * d.dh;
+    const T* qb = q + boff;
+    const T* kb = k + boff;
+    const T* vb = v + boff;
+    const T* gb = dout + (long long)b * d.S * d.ld_o + h * d.dh;
+    const float* mbase = mask ? mask + (long long)(pidx % d.B) * d.S * d.S : nullptr;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const int ks = (d.dh + 31) >> 5;
+
+    {
+        const int pt = multi ? lane : tid, pn = multi ? 64 : (int)blockDim.x;
+        stage_image(Kimg, k, d, b, h, d.ld_qkv, pt, pn);
+        stage_image(Qimg, q, d, b, h, d.ld_qkv, pt, pn);
+        stage_image(Gimg, dout, d, b, h, d.ld_o, pt, pn);
+    }
+    __syncthreads();                                           // images complete
+    // single-tile sequences (S <= 16): the row fragments of K, Q, V, dO are the same registers in both phases (A and B operands
+    // of the 16x16x32 MFMA have the same lane layout), so they are loaded once
+    Frag<T> fk[SINGLE ? 4 : 1], fq[SINGLE ? 4 : 1], fv[SINGLE ? 4 : 1], fg[SINGLE ? 4 : 1];
+
+    // ---------------- phase A: one query tile at a time, all keys (swapped orientation: rows = keys, column = query p)
+    for (int qt = wave; qt < d.nt; qt += nw) {
+        const int query = qt * 16 + p;
+        const bool qok = query < d.S;
+        float mx = 0.f, inv = 0.f;
+        if (qok) { const float* st = stats + ((long long)pidx * d.S + query) * 2; mx = st[0]; inv = 1.f / st[1]; }
+        const float* mrow = mbase ? mbase + (long long)(qok ? query : 0) * d.S : nullptr;
+        f32x4 pT[NTC], dpT[NTC];
+        float dl = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NTC; ++kt) {
+            pT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < d.nt) {
+                if (SINGLE) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (s < ks) {
+                            const int f0 = s * 32 + 8 * g;
+                            row_frag(fk[s], kb, d.ld_qkv, p, d.S, f0, d.dh);
+                            row_frag(fq[s], qb, d.ld_qkv, p, d.S, f0, d.dh);
+                            row_frag(fv[s], vb, d.ld_qkv, p, d.S, f0, d.dh);
+                            row_frag(fg[s], gb, d.ld_o, p, d.S, f0, d.dh);
+                        }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (s < ks) {
+                            pT[kt] = mma32(fk[s], fq[s], pT[kt]);
+                            dpT[kt] = mma32(fv[s], fg[s], dpT[kt]);
+                        }
+                } else {
+                    for (int s = 0; s < ks; ++s) {
+                        Frag<T> ak, bq, av, bg;
+                        const int f0 = s * 32 + 8 * g;
+                        row_frag(ak, kb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
+                        row_frag(bq, qb, d.ld_qkv, query, d.S, f0, d.dh);
+                        row_frag(av, vb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
+                        row_frag(bg, gb, d.ld_o, query, d.S, f0, d.dh);
+                        pT[kt] = mma32(ak, bq, pT[kt]);
+                        dpT[kt] = mma32(av, bg, dpT[kt]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    float sv = pT[kt][r] * scale;
+                    if (mrow && key < d.S && mrow[key] == 0.f) sv = -1e9f;
+                    float pv = (qok && key < d.S) ? __expf(sv - mx) * inv : 0.f;
+                    float dp = dpT[kt][r];
+                    if (p_drop > 0.f && qok && key < d.S)
+                        dp *= dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
+                    pT[kt][r] = pv; dpT[kt][r] = dp;
+                    dl += pv * dp;
+                }
+            }
+        }
+        dl = quad_lane_sum(dl);
+        if (g == 0) delta[qt * 16 + p] = dl;
+        Frag16<T> dsT[NTC];
+#pragma unroll
+        for (int kt = 0; kt < NTC; ++kt)
+            if (kt < d.nt) {
+                float x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = pT[kt][r] * (dpT[kt][r] - dl) * scale;
+                acc_to_frag(dsT[kt], x);
+            }
+#pragma unroll
+        for (int dt = 0; dt < MAXDT; ++dt)
+            if (dt < d.DT) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < NTC; ++kt)
+                    if (kt < d.nt) {
+                        Frag16<T> a;
+                        tr_read(a, Kimg, d.ldi, kt * 16, dt * 16, lane);      // K^T[feature][key]
+                        o = mma16(a, dsT[kt], o);
+                    }
+                const int f0 = dt * 16 + 4 * g;
+                if (valid && qok && f0 < d.dh) store4(dq + ((long long)(b * d.S + query)) * d.ld_qkv + h * d.dh + f0, o);
+            }
+    }
+    __syncthreads();                                           // delta of every query tile is in LDS
+    // ---------------- phase B: one KEY tile at a time, all query tiles (normal orientation: rows = queries, column = key p)
+    for (int kt = wave; kt < d.nt; kt += nw) {
+        const int key = kt * 16 + p;
+        const bool kok = key < d.S;
+        f32x4 dkT[SINGLE ? 1 : MAXDT], dvT[SINGLE ? 1 : MAXDT];
+#pragma unroll
+        for (int dt = 0; dt < (SINGLE ? 1 : MAXDT); ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int qt = 0; qt < d.nt; ++qt) {
+            f32x4 sN = f32x4{0.f, 0.f, 0.f, 0.f}, dpN = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SINGLE) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ks) {
+                        sN = mma32(fq[s], fk[s], sN);
+                        dpN = mma32(fg[s], fv[s], dpN);
+                    }
             } else {
-                pv = 0.f;
+                for (int s = 0; s < ks; ++s) {
+                    Frag<T> aq, bk, ag, bv;
+                    const int f0 = s * 32 + 8 * g;
+                    row_frag(aq, qb, d.ld_qkv, qt * 16 + p, d.S, f0, d.dh);
+                    row_frag(bk, kb, d.ld_qkv, key, d.S, f0, d.dh);
+                    row_frag(ag, gb, d.ld_o, qt * 16 + p, d.S, f0, d.dh);
+                    row_frag(bv, vb, d.ld_qkv, key, d.S, f0, d.dh);
+                    sN = mma32(aq, bk, sN);
+                    dpN = mma32(ag, bv, dpN);
+                }
             }
-            Pl[row * lds_ + col] = from_f32<T>(pv);
-        }
-    }
-    __syncthreads();
-
-    const int ntd = d.dhp >> 4;
-    for (int t = wave; t < nt * ntd; t += 4) {
-        const int ti = t / ntd, tj = t % ntd;
-        const f32x4 acc = mm_tile(Pl + ti * 16 * lds_, lds_, Vt + tj * 16 * lds_, lds_, d.SK, lane);
-        const int col = tj * 16 + p;
-        if (col < d.dh) {
+            float ds[4], pd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) out[((long long)(b * d.S + row)) * d.ld_o + h * d.dh + col] = from_f32<T>(acc[r]);
+                const int query = qt * 16 + 4 * g + r;
+                const bool ok = kok && query < d.S;
+                float pv = 0.f, mult = 1.f;
+                if (ok) {
+                    const float* st = stats + ((long long)pidx * d.S + query) * 2;
+                    float sv = sN[r] * scale;
+                    if (mbase && mbase[(long long)query * d.S + key] == 0.f) sv = -1e9f;
+                    pv = __expf(sv - st[0]) / st[1];
+                    if (p_drop > 0.f) mult = dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
+                }
+                ds[r] = pv * (dpN[r] * mult - delta[qt * 16 + 4 * g + r]) * scale;
+                pd[r] = pv * mult;
             }
+            Frag16<T> dsF, pdF;
+            acc_to_frag(dsF, ds);
+            acc_to_frag(pdF, pd);
+#pragma unroll
+            for (int dt = 0; dt < MAXDT; ++dt)
+                if (dt < d.DT) {
+                    Frag16<T> aq, ag;
+                    tr_read(aq, Qimg, d.ldi, qt * 16, dt * 16, lane);          // Q^T[feature][query]
+                    tr_read(ag, Gimg, d.ldi, qt * 16, dt * 16, lane);          // dO^T[feature][query]
+                    if (SINGLE) {                                              // one query tile: the tile is final, store it now (no live accumulators)
+                        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 tk = mma16(aq, dsF, z), tv = mma16(ag, pdF, z);      // matrix ops stay outside the divergent store branch
+                        const int f0 = dt * 16 + 4 * g;
+                        if (valid && kok && f0 < d.dh) {
+                            const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
+                            store4(dk + o, tk);
+                            store4(dv + o, tv);
+                        }
+                    } else {
+                        dkT[dt] = mma16(aq, dsF, dkT[dt]);
+                        dvT[dt] = mma16(ag, pdF, dvT[dt]);
+                    }
+                }
         }
+        if (!SINGLE)
+#pragma unroll
+        for (int dt = 0; dt < MAXDT; ++dt)
+            if (dt < d.DT) {
+                const int f0 = dt * 16 + 4 * g;
+                if (valid && kok && f0 < d.dh) {
+                    const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
+                    store4(dk + o, dkT[dt]);
+                    store4(dv + o, dvT[dt]);
+                }
+            }
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                            const float* __restrict__ probs, const T* __restrict__ dout,
-                                                            T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv,
-                                                            AttnDims d, float scale, float p_drop, unsigned long long seed) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int ldq = d.dhp + 8, lds_ = d.SK + 8, ldsc = d.SK + 4;
-    const int regA = 2 * d.SK * ldq, regB = d.dhp * lds_;
-    T* R1 = reinterpret_cast<T*>(smem_raw);                 // phase A: dO | V ; phase C: transposed operand
-    T* dSl = R1 + (regA > regB ? regA : regB);              // [SK][SK+8]  dS (scaled)
-    T* dSt = dSl + d.SK * lds_;                             // [SK][SK+8]  dS^T
-    T* PdT = dSt + d.SK * lds_;                             // [SK][SK+8]  (P*dropout)^T
-    float* Sc = reinterpret_cast<float*>(PdT + d.SK * lds_);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pidx = blockIdx.x, b = pidx / d.H, h = pidx % d.H;
-    const int p = lane & 15, qq = lane >> 4;
-    const int nt = d.SK >> 4, ntd = d.dhp >> 4;
-
-    // ---- phase A: dPd = dO V^T
-    T* dOl = R1;
-    T* Vl = R1 + d.SK * ldq;
-    stage_rows(dOl, ldq, dout, d, b, h, tid, d.ld_o);
-    stage_rows(Vl, ldq, v, d, b, h, tid, d.ld_qkv);
-    __syncthreads();
-    for (int t = wave; t < nt * nt; t += 4) {
-        const int ti = t / nt, tj = t % nt;
-        const f32x4 acc = mm_tile(dOl + ti * 16 * ldq, ldq, Vl + tj * 16 * ldq, ldq, d.dhp, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Sc[(ti * 16 + 4 * qq + r) * ldsc + tj * 16 + p] = acc[r];
-    }
-    __syncthreads();
-
-    // ---- phase B: softmax backward, one row per 16-lane group
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    for (int row = wave * 4 + qq; row < d.SK; row += 16) {
-        float pv[4], dp[4], mult[4];
-        float delta = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = p + 16 * c;
-            pv[c] = 0.f; dp[c] = 0.f; mult[c] = 1.f;
-            if (row < d.S && col < d.S) {
-                const long long idx = ((long long)pidx * d.S + row) * d.S + col;
-                pv[c] = probs[idx];
-                if (p_drop > 0.f) mult[c] = dropout_mult(seed, (unsigned long long)idx, p_drop, inv_keep);
-                dp[c] = Sc[row * ldsc + col] * mult[c];
-                delta += dp[c] * pv[c];
-            }
-        }
-        delta = group16_sum(delta);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = p + 16 * c;
-            if (col >= d.SK) continue;
-            const float ds = pv[c] * (dp[c] - delta) * scale;
-            const float pd = pv[c] * mult[c];
-            dSl[row * lds_ + col] = from_f32<T>(ds);
-            dSt[col * lds_ + row] = from_f32<T>(ds);
-            PdT[col * lds_ + row] = from_f32<T>(pd);
-        }
-    }
-    __syncthreads();
-
-    // ---- phase C1: dV[key][d] = sum_query PdT[key][query] * dO^T[d][query]
-    stage_cols(R1, lds_, dout, d, b, h, tid, d.ld_o);
-    __syncthreads();
-    for (int t = wave; t < nt * ntd; t += 4) {
-        const int ti = t / ntd, tj = t % ntd;
-        const f32x4 acc = mm_tile(PdT + ti * 16 * lds_, lds_, R1 + tj * 16 * lds_, lds_, d.SK, lane);
-        const int col = tj * 16 + p;
-        if (col < d.dh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dv[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase C2: dQ[query][d] = sum_key dS[query][key] * K^T[d][key]
-    stage_cols(R1, lds_, k, d, b, h, tid, d.ld_qkv);
-    __syncthreads();
-    for (int t = wave; t < nt * ntd; t += 4) {
-        const int ti = t / ntd, tj = t % ntd;
-        const f32x4 acc = mm_tile(dSl + ti * 16 * lds_, lds_, R1 + tj * 16 * lds_, lds_, d.SK, lane);
-        const int col = tj * 16 + p;
-        if (col < d.dh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dq[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase C3: dK[key][d] = sum_query dS^T[key][query] * Q^T[d][query]
-    stage_cols(R1, lds_, q, d, b, h, tid, d.ld_qkv);
-    __syncthreads();
-    for (int t = wave; t < nt * ntd; t += 4) {
-        const int ti = t / ntd, tj = t % ntd;
-        const f32x4 acc = mm_tile(dSt + ti * 16 * lds_, lds_, R1 + tj * 16 * lds_, lds_, d.SK, lane);
-        const int col = tj * 16 + p;
-        if (col < d.dh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + 4 * qq + r;
-                if (row < d.S) dk[((long long)(b * d.S + row)) * d.ld_qkv + h * d.dh + col] = from_f32<T>(acc[r]);
-            }
-        }
-    }
-}
-
-inline bool attn_dims(AttnDims& d, int B, int S, int D, int H) {
-    if (B <= 0 || S <= 0 || S > 64 || D <= 0 || H <= 0 || D % H != 0) return false;
+inline bool attn_dims(AttnDims& d, int B, int S, int D, int H, size_t es) {
+    if (B <= 0 || S <= 0 || S > 16 * MAXT || D <= 0 || H <= 0 || D % H != 0) return false;
     d.B = B; d.S = S; d.D = D; d.H = H; d.dh = D / H;
-    if (d.dh % 8 != 0 || d.dh > 128) return false;
-    d.SK = (S + 31) / 32 * 32;
-    d.dhp = (d.dh + 31) / 32 * 32;
+    if (d.dh % 8 != 0 || d.dh > 16 * MAXDT) return false;
+    d.nt = (S + 15) / 16;
+    d.DT = (d.dh + 15) / 16;
+    // row stride = an odd multiple of 32 bytes: the 8 rows x 32 B of a half-wave's transposed read then tile all 64 banks
+    int bytes = d.DT * 16 * (int)es;
+    if ((bytes / 32) % 2 == 0) bytes += 32;
+    d.ldi = bytes / (int)es;
     d.ld_qkv = D;
     d.ld_o = D;
+    // a grid of one-wave workgroups is dispatch-bound beyond a few thousand problems: pack four single-tile problems per workgroup then
+    d.ppw = (d.nt == 1 && (long long)B * H >= 2048) ? 4 : 1;
     return true;
 }
 
-template <typename T>
-size_t attn_fwd_lds(const AttnDims& d) {
-    const size_t ldq = d.dhp + 8, lds_ = d.SK + 8, ldsc = d.SK + 4;
-    return (2 * d.SK * ldq + d.dhp * lds_ + d.SK * lds_) * sizeof(T) + d.SK * ldsc * sizeof(float);
-}
-template <typename T>
-size_t attn_bwd_lds(const AttnDims& d) {
-    const size_t ldq = d.dhp + 8, lds_ = d.SK + 8, ldsc = d.SK + 4;
-    const size_t regA = 2 * d.SK * ldq, regB = d.dhp * lds_;
-    return ((regA > regB ? regA : regB) + 3 * d.SK * lds_) * sizeof(T) + d.SK * ldsc * sizeof(float);
+// waves per workgroup: default one per 16-token tile; HYB_ATTN_QROWS = 16 / 32 / 64 gives a wave that many query rows (the
+// tile-size sweep of BASELINE config 4, profiles/r02_attention_sweep.json)
+inline int attn_waves(const AttnDims& d) {
+    static const int qrows = getenv("HYB_ATTN_QROWS") ? atoi(getenv("HYB_ATTN_QROWS")) : 16;
+    const int per = qrows >= 64 ? 4 : qrows >= 32 ? 2 : 1;
+    return (d.nt + per - 1) / per;
 }
 
 template <typename T>
-int attn_fwd_t(const void* q, const void* k, const void* v, const float* mask, void* out, float* probs, const AttnDims& d, float p_drop,
+int attn_fwd_t(const void* q, const void* k, const void* v, const float* mask, void* out, float* stats, const AttnDims& d, float p_drop,
                unsigned long long seed, hipStream_t st) {
-    const size_t lds = attn_fwd_lds<T>(d);
-    if (lds > 160 * 1024) return HYB_E_ARG;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // size varies per call: not cached
-        if (e != hipSuccess) return (int)e;
-    }
+    const size_t lds = (size_t)d.ppw * d.nt * 16 * d.ldi * sizeof(T);
     const float scale = 1.0f / sqrtf((float)d.D);
-    hipLaunchKernelGGL(attention_fwd_kernel<T>, dim3(d.B * d.H), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, mask, (T*)out,
-                       probs, d, scale, p_drop, seed);
+    const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
+    if (d.nt == 1)
+        hipLaunchKernelGGL((attention_fwd_kernel<T, true>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, (T*)out, stats, d, scale,
+                           p_drop, seed);
+    else
+        hipLaunchKernelGGL((attention_fwd_kernel<T, false>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, (T*)out, stats, d, scale,
+                           p_drop, seed);
     HYB_LAUNCH_CHECK();
     return 0;
 }
 template <typename T>
-int attn_bwd_t(const void* q, const void* k, const void* v, const float* probs, const void* dout, void* dq, void* dk, void* dv,
+int attn_bwd_t(const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout, void* dq, void* dk, void* dv,
                const AttnDims& d, float p_drop, unsigned long long seed, hipStream_t st) {
-    const size_t lds = attn_bwd_lds<T>(d);
-    if (lds > 160 * 1024) return HYB_E_ARG;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attention_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    const size_t lds = (size_t)d.ppw * ((size_t)3 * d.nt * 16 * d.ldi * sizeof(T) + (size_t)d.nt * 16 * sizeof(float));     // fp32, 128-wide heads, S = 64: 104 KiB
     const float scale = 1.0f / sqrtf((float)d.D);
-    hipLaunchKernelGGL(attention_bwd_kernel<T>, dim3(d.B * d.H), dim3(256), lds, st, (const T*)q, (const T*)k, (const T*)v, probs,
-                       (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed);
+    const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
+    if (d.nt == 1) {
+        if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)attention_bwd_kernel<T, true>, 160 * 1024)) return e; }
+        hipLaunchKernelGGL((attention_bwd_kernel<T, true>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, stats,
+                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed);
+    } else {
+        if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)attention_bwd_kernel<T, false>, 160 * 1024)) return e; }
+        hipLaunchKernelGGL((attention_bwd_kernel<T, false>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, stats,
+                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed);
+    }
     HYB_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-extern "C" int hyb_attention_fwd(int dtype, const void* q, const void* k, const void* v, const float* mask, void* out, float* probs, int B,
+extern "C" int hyb_attention_fwd(int dtype, const void* q, const void* k, const void* v, const float* mask, void* out, float* stats, int B,
                                  int S, int D, int H, float p_drop, unsigned long long seed, void* stream) {
     AttnDims d;
-    HYB_CHECK_ARG(q && k && v && out && probs && attn_dims(d, B, S, D, H) && p_drop >= 0.f && p_drop < 1.f);
+    HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
+    HYB_CHECK_ARG(q && k && v && out && stats && attn_dims(d, B, S, D, H, dtype == HYB_F32 ? 4 : 2) && p_drop >= 0.f && p_drop < 1.f);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return attn_fwd_t<float>(q, k, v, mask, out, probs, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(q, k, v, mask, out, probs, d, p_drop, seed, st);
-    return HYB_E_ARG;
+    if (dtype == HYB_F32) return attn_fwd_t<float>(q, k, v, mask, out, stats, d, p_drop, seed, st);
+    return attn_fwd_t<bf16>(q, k, v, mask, out, stats, d, p_drop, seed, st);
 }
 
-extern "C" int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* probs, const void* dout, void* dq,
-                                 void* dk, void* dv, int B, int S, int D, int H, float p_drop, unsigned long long seed, void* stream) {
+extern "C" int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout,
+                                 void* dq, void* dk, void* dv, int B, int S, int D, int H, float p_drop, unsigned long long seed, void* stream) {
     AttnDims d;
-    HYB_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv && attn_dims(d, B, S, D, H) && p_drop >= 0.f && p_drop < 1.f);
+    HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
+    HYB_CHECK_ARG(q && k && v && stats && dout && dq && dk && dv && attn_dims(d, B, S, D, H, dtype == HYB_F32 ? 4 : 2) && p_drop >= 0.f && p_drop < 1.f);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return attn_bwd_t<float>(q, k, v, probs, dout, dq, dk, dv, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(q, k, v, probs, dout, dq, dk, dv, d, p_drop, seed, st);
-    return HYB_E_ARG;
+    if (dtype == HYB_F32) return attn_bwd_t<float>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, st);
+    return attn_bwd_t<bf16>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, st);
 }
 
 // Internal (same shared object): q/k/v (and dq/dk/dv) packed as [B*S][3D] -- used by hyb_encoder_{fwd,bwd}
-int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* probs, int B, int S, int D, int H, float p_drop,
+int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
                              unsigned long long seed, hipStream_t st) {
     AttnDims d;
-    if (!qkv || !out || !probs || !attn_dims(d, B, S, D, H)) return HYB_E_ARG;
-    d.ld_qkv = 3 * D;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
+    if (!qkv || !out || !stats || !attn_dims(d, B, S, D, H, es)) return HYB_E_ARG;
+    d.ld_qkv = 3 * D;
     const char* base = (const char*)qkv;
-    if (dtype == HYB_F32) return attn_fwd_t<float>(base, base + D * es, base + 2 * D * es, mask, out, probs, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, out, probs, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_fwd_t<float>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, st);
+    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, st);
     return HYB_E_ARG;
 }
-int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int S, int D, int H,
-                             float p_drop, unsigned long long seed, hipStream_t st) {
+int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
+                             int H, float p_drop, unsigned long long seed, hipStream_t st) {
     AttnDims d;
-    if (!qkv || !probs || !dout || !dqkv || !attn_dims(d, B, S, D, H)) return HYB_E_ARG;
-    d.ld_qkv = 3 * D;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
+    if (!qkv || !stats || !dout || !dqkv || !attn_dims(d, B, S, D, H, es)) return HYB_E_ARG;
+    d.ld_qkv = 3 * D;
     const char* base = (const char*)qkv;
     char* g = (char*)dqkv;
-    if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, probs, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, probs, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
+    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
     return HYB_E_ARG;
 }

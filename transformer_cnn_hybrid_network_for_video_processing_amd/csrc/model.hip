@@ -18,10 +18,10 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
-int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* probs, int B, int S, int D, int H, float p_drop,
+int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
                              unsigned long long seed, hipStream_t st);
-int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int S, int D, int H,
-                             float p_drop, unsigned long long seed, hipStream_t st);
+int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
+                             int H, float p_drop, unsigned long long seed, hipStream_t st);
 int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
                       float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -58,7 +58,7 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     L.x_in = take(M * D * es);
     L.qkv = take(M * 3 * D * es);                  // post-ReLU q | k | v, token-major [M][3D]
-    L.probs = take((size_t)B * H * S * S * 4);
+    L.probs = take((size_t)B * H * S * 2 * 4);       // softmax row statistics (max, sum) per (clip, head, query): P is recomputed in backward
     L.attn = take(M * D * es);
     L.o = take(M * D * es);
     L.st1 = take(2 * M * 4);
@@ -231,7 +231,6 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
 extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                                const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                                unsigned long long seed, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)mask;
     HYB_CHECK_ARG(dout && params && grads && saved && dx && workspace && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     if (workspace_bytes < hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) return HYB_E_WORKSPACE;
@@ -277,7 +276,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         { const void* A_[1] = {g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
         // attention core: d(q|k|v) packed [M][3D]
-        HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
+        HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
                                          attn_seed(seed, i), st));
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM, one grouped dW/db launch
         { const void* A_[1] = {dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};

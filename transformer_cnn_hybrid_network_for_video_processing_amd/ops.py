@@ -454,7 +454,7 @@ def mha_op(q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], par
     dev, tdt, M = q_in.device, _TORCH_DTYPE[dt], B * S
     ps = [t.contiguous() for t in params]
     q, k, v, a, out = (torch.empty(B, S, D, dtype=tdt, device=dev) for _ in range(5))
-    probs = torch.empty(B * H, S, S, dtype=torch.float32, device=dev)
+    probs = torch.empty(B * H, S, 2, dtype=torch.float32, device=dev)       # softmax row statistics (max, sum)
     st = _stream()
     for src, W_, b_, dst in ((q_in, ps[0], ps[1], q), (k_in, ps[2], ps[3], k), (v_in, ps[4], ps[5], v)):
         lib.call("hyb_linear_fwd", dt, src.data_ptr(), D, W_.data_ptr(), b_.data_ptr(), dst.data_ptr(), M, D, D, 1, st)
@@ -467,11 +467,11 @@ def mha_op(q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], par
 def mha_fake(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed):
     B, S, D = q_in.shape
     e = lambda: q_in.new_empty((B, S, D), dtype=_TORCH_DTYPE[dt])
-    return e(), e(), e(), e(), e(), q_in.new_empty((B * H, S, S), dtype=torch.float32)
+    return e(), e(), e(), e(), e(), q_in.new_empty((B * H, S, 2), dtype=torch.float32)
 
 
-def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, q: Tensor, k: Tensor, v: Tensor, a: Tensor, probs: Tensor,
-               params: Sequence[Tensor], dt: int, H: int, p_drop: float, seed: int) -> List[Tensor]:
+def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], q: Tensor, k: Tensor, v: Tensor, a: Tensor,
+               probs: Tensor, params: Sequence[Tensor], dt: int, H: int, p_drop: float, seed: int) -> List[Tensor]:
     """-> [dq_in, dk_in, dv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo]"""
     _require_cuda(dout, q)
     B, S, D = q.shape
@@ -484,7 +484,7 @@ def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, q: Tensor
     ws = _ws(M * D * 4, dev)
     lib.call("hyb_linear_bwd", dt, a.data_ptr(), D, ps[6].data_ptr(), None, dout.data_ptr(), da.data_ptr(), 0, grads[6].data_ptr(),
              grads[7].data_ptr(), M, D, D, 0, None, 0, st)
-    lib.call("hyb_attention_bwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), da.data_ptr(), dq.data_ptr(),
+    lib.call("hyb_attention_bwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), _opt_ptr(mask), probs.data_ptr(), da.data_ptr(), dq.data_ptr(),
              dk.data_ptr(), dv.data_ptr(), B, S, D, H, float(p_drop), seed, st)
     for src, y, dy, dsrc, iw in ((q_in, q, dq, dqi, 0), (k_in, k, dk, dki, 2), (v_in, v, dv, dvi, 4)):
         lib.call("hyb_linear_bwd", dt, src.contiguous().data_ptr(), D, ps[iw].data_ptr(), y.data_ptr(), dy.data_ptr(), dsrc.data_ptr(), 0,
@@ -492,7 +492,7 @@ def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, q: Tensor
     return [dqi, dki, dvi] + grads
 
 
-def mha_bwd_fake(dout, q_in, k_in, v_in, q, k, v, a, probs, params, dt, H, p_drop, seed):
+def mha_bwd_fake(dout, q_in, k_in, v_in, mask, q, k, v, a, probs, params, dt, H, p_drop, seed):
     return [torch.empty_like(q) for _ in range(3)] + [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
 
 
@@ -909,15 +909,20 @@ class _MhaFn(torch.autograd.Function):
     def forward(ctx, q_in, k_in, v_in, mask, dt, H, p_drop, seed, *params):
         with _below_autograd():
             out = torch.ops.hybrid.mha(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed)
-        ctx.save_for_backward(q_in, k_in, v_in, *out[1:], *params)
-        ctx.cfg = (dt, H, p_drop, seed)
+        if mask is None:
+            ctx.save_for_backward(q_in, k_in, v_in, *out[1:], *params)
+        else:
+            ctx.save_for_backward(mask, q_in, k_in, v_in, *out[1:], *params)
+        ctx.cfg = (mask is not None, dt, H, p_drop, seed)
         ctx.mark_non_differentiable(*out[1:])
         return out
 
     @staticmethod
     def backward(ctx, dout, *unused):
-        q_in, k_in, v_in, q, k, v, a, probs, *ps = ctx.saved_tensors
-        res = torch.ops.hybrid.mha_bwd(dout, q_in, k_in, v_in, q, k, v, a, probs, ps, *ctx.cfg)
+        t = list(ctx.saved_tensors)
+        mask = t.pop(0) if ctx.cfg[0] else None
+        q_in, k_in, v_in, q, k, v, a, probs, *ps = t
+        res = torch.ops.hybrid.mha_bwd(dout, q_in, k_in, v_in, mask, q, k, v, a, probs, ps, *ctx.cfg[1:])
         return (res[0], res[1], res[2]) + (None,) * 5 + tuple(res[3:])
 
 
@@ -1016,7 +1021,7 @@ _define("encoder_bwd", "(Tensor dout, Tensor? mask, Tensor[] params, Tensor save
 _define("mha", "(Tensor q_in, Tensor k_in, Tensor v_in, Tensor? mask, Tensor[] params, int dt, int H, float p_drop, int seed) -> "
         "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", mha_op, mha_fake,
         lambda q, k, v, mask, params, dt, H, p_drop, seed: _MhaFn.apply(q, k, v, mask, dt, H, p_drop, seed, *params))
-_define("mha_bwd", "(Tensor dout, Tensor q_in, Tensor k_in, Tensor v_in, Tensor q, Tensor k, Tensor v, Tensor a, Tensor probs, Tensor[] params, "
+_define("mha_bwd", "(Tensor dout, Tensor q_in, Tensor k_in, Tensor v_in, Tensor? mask, Tensor q, Tensor k, Tensor v, Tensor a, Tensor probs, Tensor[] params, "
         "int dt, int H, float p_drop, int seed) -> Tensor[]", mha_bwd_op, mha_bwd_fake)
 _define("head", "(Tensor x, Tensor weight, Tensor? bias, int dt) -> Tensor", head_op, head_fake, _HeadFn.apply)
 _define("head_bwd", "(Tensor dlogits, Tensor x, Tensor weight, bool has_bias, int dt) -> (Tensor, Tensor, Tensor)", head_bwd_op, head_bwd_fake)
