@@ -62,6 +62,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fwd-bwd-only", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python each step instead of replaying the captured hipGraphs "
+                                                         "(graph.GraphedTrainStep); same kernels and arithmetic, more host time")
     args = ap.parse_args(argv)
     c = CONFIGS[args.config]
     for flag, key in (("batch", "batch"), ("frames", "frames"), ("size", "size"), ("d_model", "d_model"), ("heads", "num_heads"), ("hidden", "hidden_dim")):
@@ -335,29 +337,36 @@ def main():
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)  # stock torch optimizer, fused multi-tensor kernels
         except Exception:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
-    reducer = GradAllReducer(model) if world > 1 else None
+    graphed = not args.eager and args.optimizer == "hybrid"
+    reducer = GradAllReducer(model) if world > 1 and not graphed else None
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)          # rank r seeds its own clips
     x = torch.rand(args.batch, args.frames, 3, args.size, args.size, generator=g).to(dev)
     y = torch.randint(0, CFG["num_classes"], (args.batch,), generator=g).to(dev)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = crit(model(x), y)
-        loss.backward()
-        if reducer is not None:
-            reducer.finalize()
-        opt.step()
-        return loss
+    if graphed:
+        # the whole step captured once as three hipGraphs (forward + temporal backward | backbone backward | AdamW); the gradient
+        # all-reduce runs between them, outside the graphs, overlapped with the backbone backward (graph.py)
+        trainer = P.GraphedTrainStep(model, crit, opt, x, y)
+        step, fwd_bwd = trainer.step, trainer.fwd_bwd
+    else:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(x), y)
+            loss.backward()
+            if reducer is not None:
+                reducer.finalize()
+            opt.step()
+            return loss
 
-    def fwd_bwd():                              # the metric's literal "fwd+bwd": gradients (all-reduced when N>1), no optimizer
-        for p in params:
-            p.grad = None
-        loss = crit(model(x), y)
-        loss.backward()
-        if reducer is not None:
-            reducer.finalize()
-        return loss
+        def fwd_bwd():                              # the metric's literal "fwd+bwd": gradients (all-reduced when N>1), no optimizer
+            for p in params:
+                p.grad = None
+            loss = crit(model(x), y)
+            loss.backward()
+            if reducer is not None:
+                reducer.finalize()
+            return loss
     params = list(model.parameters())
 
     def barrier():
@@ -418,6 +427,7 @@ def main():
                                    f"CNN 32-64-128-256 + 2-layer transformer d={args.d_model} h={args.heads} hid={args.hidden}, 8 classes",
                        "global_batch": args.batch * world, "frames": args.frames,
                        "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw",
+                       "launch": "3 replayed hipGraphs per step (graph.GraphedTrainStep)" if graphed else "eager (one Python-issued launch per kernel)",
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",
@@ -427,7 +437,7 @@ def main():
         if fb is not None:
             out["fwd_bwd_only"] = fb
         if not args.no_roofline and world == 1:
-            rows = instep_kernel_table(args, step)
+            rows = instep_kernel_table(args, trainer.eager_fwd_bwd if graphed else step)
             dom = dominant_kernel(rows)
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12

@@ -215,15 +215,18 @@ int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, const float* g
  *   W1,b1,W2,b2 (feedforward_layers.i.{0,2}.{weight,bias}), ln_w, ln_b (layer_norm.i).
  * grads: same order, fp32, overwritten.  saved: caller buffer of hyb_encoder_saved_bytes.
  * attn_p = attention-weight dropout (0.1 in train mode, 0 in eval: quirk Q5);
- * layer_p = per-layer dropout (always active: quirk Q6). */
+ * layer_p = per-layer dropout (always active: quirk Q6).
+ * seed_inc: NULL, or a DEVICE pointer to one 64-bit counter that the kernels add to `seed` when they run.  A launch captured
+ * in a hipGraph replays with the same by-value `seed`; advancing the counter between replays (any kernel on the stream) gives
+ * every replay its own dropout masks.  Pass the same pointer (and value) to the backward call of the same step. */
 size_t hyb_encoder_saved_bytes(int dtype, int B, int S, int D, int Hid, int L, int H);
 size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, int Hid, int L, int H);
 int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out,
                     void* saved, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
-                    unsigned long long seed, void* stream);
+                    unsigned long long seed, const unsigned long long* seed_inc, void* stream);
 int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params,
                     float* const* grads, const void* saved, void* dx, int B, int S, int D, int Hid, int L,
-                    int H, float attn_p, float layer_p, unsigned long long seed,
+                    int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- head: mean over T then Linear(d, classes) (composite's own) ---------------------- */
@@ -268,22 +271,24 @@ int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpo
 int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
                      const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
                      void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
-                     float attn_p, float layer_p, unsigned long long seed, void* stream);
+                     float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream);
 size_t hyb_temporal_bwd_workspace(int dtype, int B, int S, int HW, int Cp, int D, int Hid, int L, int H);
 int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, const float* const* enc_params, const float* head_w,
                      const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
                      float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
                      int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
  * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
  * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]
  * elements); state tensors are caller-owned and must be zero before step 1.  Hyper-parameters are doubles (Python floats):
- * 1 - beta etc. are formed in double and rounded to fp32 once, like torch does. */
+ * 1 - beta etc. are formed in double and rounded to fp32 once, like torch does.
+ * step_inc: NULL, or a DEVICE pointer to one 64-bit counter: the step number used is step + *step_inc, read when the kernel runs
+ * (the bias corrections are then formed on the device, in double) -- lets one captured launch serve every replay of a hipGraph. */
 int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                    const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
-                   void* stream);
+                   const long long* step_inc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,5 +2,6 @@
 from .modules import (ConvBNReLUPool, HybridCrossEntropyLoss, MultiheadAttention, TransformerCNNHybrid,  # noqa: F401
                       TransformerEncoder)
 from .optim import HybridAdamW  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
 
-__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW"]
+__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW", "GraphedTrainStep"]

@@ -117,7 +117,8 @@ constexpr int MAXDT = 8;      // head width <= 128
 // SINGLE: S <= 16 (one token tile): the tile loops collapse at compile time and the kernel fits 128 VGPRs (4 waves per SIMD)
 template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
-                                     T* __restrict__ out, float* __restrict__ stats, AttnDims d, float scale, float p_drop, unsigned long long seed) {
+                                     T* __restrict__ out, float* __restrict__ stats, AttnDims d, float scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    if (seed_inc) seed += *seed_inc;                            // device-side step counter (captured launches draw a fresh mask per replay)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NTC = SINGLE ? 1 : MAXT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(cons
 template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
                                      const float* __restrict__ stats, const T* __restrict__ dout, T* __restrict__ dq, T* __restrict__ dk,
-                                     T* __restrict__ dv, AttnDims d, float scale, float p_drop, unsigned long long seed) {
+                                     T* __restrict__ dv, AttnDims d, float scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    if (seed_inc) seed += *seed_inc;                            // device-side step counter (captured launches draw a fresh mask per replay)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NTC = SINGLE ? 1 : MAXT;
     const int rows = d.nt * 16;
@@ -450,33 +452,33 @@ inline int attn_waves(const AttnDims& d) {
 
 template <typename T>
 int attn_fwd_t(const void* q, const void* k, const void* v, const float* mask, void* out, float* stats, const AttnDims& d, float p_drop,
-               unsigned long long seed, hipStream_t st) {
+               unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
     const size_t lds = (size_t)d.ppw * d.nt * 16 * d.ldi * sizeof(T);
     const float scale = 1.0f / sqrtf((float)d.D);
     const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
     if (d.nt == 1)
         hipLaunchKernelGGL((attention_fwd_kernel<T, true>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, (T*)out, stats, d, scale,
-                           p_drop, seed);
+                           p_drop, seed, seed_inc);
     else
         hipLaunchKernelGGL((attention_fwd_kernel<T, false>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, (T*)out, stats, d, scale,
-                           p_drop, seed);
+                           p_drop, seed, seed_inc);
     HYB_LAUNCH_CHECK();
     return 0;
 }
 template <typename T>
 int attn_bwd_t(const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout, void* dq, void* dk, void* dv,
-               const AttnDims& d, float p_drop, unsigned long long seed, hipStream_t st) {
+               const AttnDims& d, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
     const size_t lds = (size_t)d.ppw * ((size_t)3 * d.nt * 16 * d.ldi * sizeof(T) + (size_t)d.nt * 16 * sizeof(float));     // fp32, 128-wide heads, S = 64: 104 KiB
     const float scale = 1.0f / sqrtf((float)d.D);
     const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
     if (d.nt == 1) {
         if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)attention_bwd_kernel<T, true>, 160 * 1024)) return e; }
         hipLaunchKernelGGL((attention_bwd_kernel<T, true>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, stats,
-                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed);
+                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed, seed_inc);
     } else {
         if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)attention_bwd_kernel<T, false>, 160 * 1024)) return e; }
         hipLaunchKernelGGL((attention_bwd_kernel<T, false>), grid, block, lds, st, (const T*)q, (const T*)k, (const T*)v, mask, stats,
-                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed);
+                           (const T*)dout, (T*)dq, (T*)dk, (T*)dv, d, scale, p_drop, seed, seed_inc);
     }
     HYB_LAUNCH_CHECK();
     return 0;
@@ -490,8 +492,8 @@ extern "C" int hyb_attention_fwd(int dtype, const void* q, const void* k, const 
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(q && k && v && out && stats && attn_dims(d, B, S, D, H, dtype == HYB_F32 ? 4 : 2) && p_drop >= 0.f && p_drop < 1.f);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return attn_fwd_t<float>(q, k, v, mask, out, stats, d, p_drop, seed, st);
-    return attn_fwd_t<bf16>(q, k, v, mask, out, stats, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_fwd_t<float>(q, k, v, mask, out, stats, d, p_drop, seed, nullptr, st);
+    return attn_fwd_t<bf16>(q, k, v, mask, out, stats, d, p_drop, seed, nullptr, st);
 }
 
 extern "C" int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout,
@@ -500,31 +502,31 @@ extern "C" int hyb_attention_bwd(int dtype, const void* q, const void* k, const 
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(q && k && v && stats && dout && dq && dk && dv && attn_dims(d, B, S, D, H, dtype == HYB_F32 ? 4 : 2) && p_drop >= 0.f && p_drop < 1.f);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == HYB_F32) return attn_bwd_t<float>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, st);
-    return attn_bwd_t<bf16>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_bwd_t<float>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, nullptr, st);
+    return attn_bwd_t<bf16>(q, k, v, mask, stats, dout, dq, dk, dv, d, p_drop, seed, nullptr, st);
 }
 
 // Internal (same shared object): q/k/v (and dq/dk/dv) packed as [B*S][3D] -- used by hyb_encoder_{fwd,bwd}
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
-                             unsigned long long seed, hipStream_t st) {
+                             unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
     AttnDims d;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     if (!qkv || !out || !stats || !attn_dims(d, B, S, D, H, es)) return HYB_E_ARG;
     d.ld_qkv = 3 * D;
     const char* base = (const char*)qkv;
-    if (dtype == HYB_F32) return attn_fwd_t<float>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_fwd_t<float>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, seed_inc, st);
+    if (dtype == HYB_BF16) return attn_fwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, out, stats, d, p_drop, seed, seed_inc, st);
     return HYB_E_ARG;
 }
 int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
-                             int H, float p_drop, unsigned long long seed, hipStream_t st) {
+                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
     AttnDims d;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     if (!qkv || !stats || !dout || !dqkv || !attn_dims(d, B, S, D, H, es)) return HYB_E_ARG;
     d.ld_qkv = 3 * D;
     const char* base = (const char*)qkv;
     char* g = (char*)dqkv;
-    if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
-    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, st);
+    if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, seed_inc, st);
+    if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, seed_inc, st);
     return HYB_E_ARG;
 }

@@ -101,12 +101,12 @@ extern "C" size_t hyb_temporal_bwd_workspace(int dtype, int B, int S, int HW, in
 extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
                                 const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
                                 void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
-                                float attn_p, float layer_p, unsigned long long seed, void* stream) {
+                                float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream) {
     HYB_CHECK_ARG(h && token_w && enc_params && head_w && feat && tok && enc_saved && enc_out && logits && B > 0 && S > 0 && HW > 0);
     const int N = B * S;
     HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
     HYB_TRY(hyb_linear_fwd(dtype, feat, Cp, token_w, token_b, tok, N, D, C, 0, stream));
-    HYB_TRY(hyb_encoder_fwd(dtype, tok, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, stream));
+    HYB_TRY(hyb_encoder_fwd(dtype, tok, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream));
     HYB_TRY(hyb_head_fwd(dtype, enc_out, head_w, head_b, logits, B, S, D, classes, stream));
     return 0;
 }
@@ -115,7 +115,7 @@ extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* to
                                 const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
                                 float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
                                 int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(dlogits && token_w && enc_params && head_w && feat && enc_saved && enc_out && dtoken_w && enc_grads && dhead_w && dh && workspace);
     if (workspace_bytes < hyb_temporal_bwd_workspace(dtype, B, S, HW, Cp, D, Hid, L, H)) return HYB_E_WORKSPACE;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -126,7 +126,7 @@ extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* to
     void* dtok = ws + enc_ws + al256((size_t)N * D * es);       // d(tokens)
     void* dfeat = ws + enc_ws + 2 * al256((size_t)N * D * es);  // d(frame features), padded channels zero
     HYB_TRY(hyb_head_bwd(dtype, enc_out, head_w, dlogits, denc, dhead_w, dhead_b, B, S, D, classes, stream));
-    HYB_TRY(hyb_encoder_bwd(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, ws, enc_ws, stream));
+    HYB_TRY(hyb_encoder_bwd(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws, enc_ws, stream));
     if (Cp > C) { hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)N * Cp * es, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, dtoken_w, dtoken_b, N, D, C, 0, nullptr, 0, stream));
     HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));

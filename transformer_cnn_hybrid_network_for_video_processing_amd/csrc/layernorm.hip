@@ -12,7 +12,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               T* __restrict__ y, float* __restrict__ stats, int M, int D, float eps,
-                                                              float out_scale, float p_drop, unsigned long long seed) {
+                                                              float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    if (seed_inc) seed += *seed_inc;                            // device-side step counter: the same captured launch draws a fresh mask per replay
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -66,7 +67,8 @@ template <typename T, bool ROWS>
 __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip,
                                                               int accumulate_dskip, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int M, int D, float out_scale, float p_drop, unsigned long long seed) {
+                                                              int M, int D, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    if (seed_inc) seed += *seed_inc;                            // device-side step counter: the same captured launch draws a fresh mask per replay
     const int lane = threadIdx.x & 63;
     const int nchunk = D >> 3;
     const int total_waves = gridDim.x * 4;
@@ -283,15 +285,23 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long*
 
 }  // namespace
 
+int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats,
+                            int M, int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc,
+                            void* stream);
 extern "C" int hyb_ln_residual_fwd(int dtype, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats,
                                    int M, int D, float eps, float out_scale, float p_drop, unsigned long long seed, void* stream) {
+    return hyb_ln_residual_fwd_inc(dtype, x, skip, gamma, beta, y, stats, M, D, eps, out_scale, p_drop, seed, nullptr, stream);
+}
+int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats,
+                            int M, int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc,
+                            void* stream) {
     HYB_CHECK_ARG(x && skip && gamma && beta && y && stats && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC && p_drop >= 0.f && p_drop < 1.f);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(hyb_cdiv(M, 4));
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL(ln_residual_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)skip, gamma, beta, (float*)y, stats, M, D, eps, out_scale, p_drop, seed);
+        hipLaunchKernelGGL(ln_residual_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)skip, gamma, beta, (float*)y, stats, M, D, eps, out_scale, p_drop, seed, seed_inc);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL(ln_residual_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)skip, gamma, beta, (bf16*)y, stats, M, D, eps, out_scale, p_drop, seed);
+        hipLaunchKernelGGL(ln_residual_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)skip, gamma, beta, (bf16*)y, stats, M, D, eps, out_scale, p_drop, seed, seed_inc);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
@@ -306,9 +316,9 @@ extern "C" int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, con
     if (blocks > 32) blocks = 32;
     const size_t lnlds = 2 * (size_t)D * sizeof(float);
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, false>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, false>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed, (const unsigned long long*)nullptr);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, false>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, false>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, dgamma, dbeta, M, D, out_scale, p_drop, seed, (const unsigned long long*)nullptr);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
@@ -318,15 +328,15 @@ extern "C" int hyb_ln_residual_bwd(int dtype, const void* dy, const void* x, con
 // hyb_ln_rows_reduce sums any number of such rows into dgamma/dbeta (overwriting them).
 int hyb_ln_bwd_rows(int M) { int b = hyb_cdiv(M, 4); return b > 32 ? 32 : b; }
 int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
-                             int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed,
+                             int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc,
                              hipStream_t st) {
     HYB_CHECK_ARG(dy && x && gamma && stats && dx && dskip && part && M > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC);
     const int blocks = hyb_ln_bwd_rows(M);
     const size_t lnlds = 8 * (size_t)D * sizeof(float);
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, true>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<float, true>), dim3(blocks), dim3(256), lnlds, st, (const float*)dy, (const float*)x, gamma, stats, (float*)dx, (float*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed, seed_inc);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, true>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed);
+        hipLaunchKernelGGL((ln_residual_bwd_kernel<bf16, true>), dim3(blocks), dim3(256), lnlds, st, (const bf16*)dy, (const bf16*)x, gamma, stats, (bf16*)dx, (bf16*)dskip, accumulate_dskip, part, (float*)nullptr, M, D, out_scale, p_drop, seed, seed_inc);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;

@@ -12,16 +12,19 @@ int hyb_convert_weights(int dtype, int count, const float* const* W, void* const
 int hyb_ln_bwd_rows(int M);
 int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
                              int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed,
-                             hipStream_t st);
+                             const unsigned long long* seed_inc, hipStream_t st);
+int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats,
+                            int M, int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc,
+                            void* stream);
 int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
-                             unsigned long long seed, hipStream_t st);
+                             unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
 int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
-                             int H, float p_drop, unsigned long long seed, hipStream_t st);
+                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
 int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
                       float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -184,7 +187,7 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
 }
 
 extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
-                               int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, void* stream) {
+                               int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream) {
     HYB_CHECK_ARG(x && params && out && saved && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(D % 8 == 0 && Hid % 8 == 0);
@@ -213,24 +216,24 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
         void* ys[3] = {base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es};
         HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, 3 * D, 1, 0, st));                           // src L69-70
         HYB_TRY(hyb_attention_fwd_packed(dtype, base + lay.qkv, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p,
-                                         attn_seed(seed, i), st));                                                    // src L73-84
+                                         attn_seed(seed, i), seed_inc, st));                                          // src L73-84
         { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, D, D, D, D, 0, 0, st)); }                            // src L87
-        HYB_TRY(hyb_ln_residual_fwd(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
-                                    0ull, stream));                                                                   // src L116-117
+        HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
+                                        0ull, nullptr, stream));                                                                   // src L116-117
         { const void* A_[1] = {base + lay.x1}; const void* B_[1] = {base + lay.wc[4]}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st)); }                        // src L119 (Linear, ReLU)
         { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {base + lay.wc[5]}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, Hid, Hid, Hid, D, 0, 0, st)); }                      // src L119 (Linear)
-        HYB_TRY(hyb_ln_residual_fwd(dtype, base + lay.f, base + lay.x1, P[12], P[13], y_out, (float*)(base + lay.st2), M, D, 1e-5f,
-                                    (float)sqrt(0.5), layer_p, drop_seed(seed, i), stream));                          // src L120-123
+        HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.f, base + lay.x1, P[12], P[13], y_out, (float*)(base + lay.st2), M, D, 1e-5f,
+                                        (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, stream));                          // src L120-123
     }
     return 0;
 }
 
 extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                                const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
-                               unsigned long long seed, void* workspace, size_t workspace_bytes, void* stream) {
+                               unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(dout && params && grads && saved && dx && workspace && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     if (workspace_bytes < hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) return HYB_E_WORKSPACE;
@@ -260,7 +263,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         void* gx = (i == 0) ? dx : gin[i & 1];
         // LN2 + residual + sqrt(.5) + dropout
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, lnpart, M, D,
-                                         (float)sqrt(0.5), layer_p, drop_seed(seed, i), st));
+                                         (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, st));
         // FFN second Linear: dX = g1 . W2 (pre-transposed copy), dW/db in one launch
         { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {dh};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
@@ -269,7 +272,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
         // LN1 + residual
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1b, gx, 0,
-                                         lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, st));
+                                         lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, nullptr, st));
         // the layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients, fixed order
         HYB_TRY(hyb_ln_rows_reduce(lnpart, 2 * lnrows, D, G[12], G[13], st));
         // output projection
@@ -277,7 +280,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
         // attention core: d(q|k|v) packed [M][3D]
         HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
-                                         attn_seed(seed, i), st));
+                                         attn_seed(seed, i), seed_inc, st));
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM, one grouped dW/db launch
         { const void* A_[1] = {dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }

@@ -17,17 +17,33 @@ struct AdamArgs {
     int chunk_begin[ADAM_MAX + 1];
     int count;
     float decay, omb1, beta2, omb2, eps, step_size, inv_sqrt_bc2;      // omb = 1 - beta, formed in double on the host like torch does
+    // device-side step counter (hipGraph replays): when step_inc != NULL the bias corrections are formed on the device, in double,
+    // from step + *step_inc
+    const long long* step_inc;
+    long long step;
+    double lr, beta1d, beta2d;
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float step_size, float inv_sqrt_bc2) {
     p *= a.decay;
     m = m + a.omb1 * (g - m);
     v = a.beta2 * v + a.omb2 * g * g;
-    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
-    p -= a.step_size * (m / denom);
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    p -= step_size * (m / denom);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    __shared__ float s_corr[2];
+    float step_size = a.step_size, inv_sqrt_bc2 = a.inv_sqrt_bc2;
+    if (a.step_inc) {                                          // uniform branch: every thread reaches the barrier
+        if (threadIdx.x == 0) {
+            const double t = (double)(a.step + *a.step_inc);
+            s_corr[0] = (float)(a.lr / (1.0 - pow(a.beta1d, t)));
+            s_corr[1] = (float)(1.0 / sqrt(1.0 - pow(a.beta2d, t)));
+        }
+        __syncthreads();
+        step_size = s_corr[0]; inv_sqrt_bc2 = s_corr[1];
+    }
     int ti = 0;
     for (int i = 1; i < a.count; ++i)
         if ((int)blockIdx.x >= a.chunk_begin[i]) ti = i;
@@ -42,10 +58,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
             f32x4 p = *reinterpret_cast<f32x4*>(t.p + i), m = *reinterpret_cast<f32x4*>(t.m + i), v = *reinterpret_cast<f32x4*>(t.v + i);
             const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float pj = p[j], mj = m[j], vj = v[j]; adam_one(pj, g[j], mj, vj, a); p[j] = pj; m[j] = mj; v[j] = vj; }
+            for (int j = 0; j < 4; ++j) { float pj = p[j], mj = m[j], vj = v[j]; adam_one(pj, g[j], mj, vj, a, step_size, inv_sqrt_bc2); p[j] = pj; m[j] = mj; v[j] = vj; }
             *reinterpret_cast<f32x4*>(t.p + i) = p; *reinterpret_cast<f32x4*>(t.m + i) = m; *reinterpret_cast<f32x4*>(t.v + i) = v;
         } else {
-            for (long long e = i; e < i + 4 && e < t.n; ++e) adam_one(t.p[e], t.g[e], t.m[e], t.v[e], a);
+            for (long long e = i; e < i + 4 && e < t.n; ++e) adam_one(t.p[e], t.g[e], t.m[e], t.v[e], a, step_size, inv_sqrt_bc2);
         }
     }
 }
@@ -54,7 +70,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 extern "C" int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                               const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
-                              void* stream) {
+                              const long long* step_inc, void* stream) {
     HYB_CHECK_ARG(count > 0 && params && grads && exp_avg && exp_avg_sq && numel && step >= 1 && lr >= 0.0);
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     for (int first = 0; first < count; first += ADAM_MAX) {
@@ -74,6 +90,7 @@ extern "C" int hyb_adamw_step(int count, float* const* params, const float* cons
         a.omb1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
         a.step_size = (float)(lr / bc1);
         a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        a.step_inc = step_inc; a.step = step; a.lr = lr; a.beta1d = beta1; a.beta2d = beta2;
         hipLaunchKernelGGL(adamw_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
         HYB_LAUNCH_CHECK();
     }

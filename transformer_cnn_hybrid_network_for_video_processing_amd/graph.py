@@ -1,0 +1,174 @@
+"""The training step as replayed hipGraphs: zero_grad -> forward -> cross-entropy -> backward -> (gradient all-reduce) -> AdamW.
+
+Why: the step is ~90 small-to-medium kernel launches; issued eagerly they cost the host 1.4 ms of Python + launch time for ~1.6 ms
+of GPU work (scripts/host_jitter.py), so any kernel speed-up beyond ~15 % -- and any slower host, e.g. 8 ranks sharing one
+machine -- would leave the GPU waiting.  Captured once (torch.cuda.graphs = HIP stream capture) the step is three graph launches.
+
+The reference has nothing comparable (single process, eager); this is host-side scheduling only: the
+kernels, their order and their arithmetic are exactly those of the eager step, so results are bit-identical to eager for the
+same dropout seeds.
+
+What makes capture legal here
+  * every buffer an operator needs is a torch allocation made during capture (graph-private pool): nothing is allocated or
+    freed by the library, and no call synchronises;
+  * step-dependent scalars live on the device: the kernels add a device counter to their by-value dropout seed, and AdamW forms
+    its bias corrections from state['step'] + counter on the device (hyb_*'s seed_inc / step_inc arguments).  The counter is
+    advanced inside the last graph, so every replay is a new step with new masks;
+  * BatchNorm running statistics are written by the captured multi-tensor copy of ops.commit_running_stats.
+
+Data parallelism (world > 1): the backward pass is captured in two pieces so that the gradient all-reduce of the temporal part
+(25 of the 27 MB) runs -- eagerly, on the collective's own stream, outside any graph, so any torch.distributed backend works --
+while the CNN backbone's backward graph executes:
+
+    graph A: forward, loss, backward of head + encoder + token projection  -> their gradients in the "temporal" bucket
+    all_reduce(temporal bucket, async)                                      [RCCL / xGMI]
+    graph B: backward of the conv stages                                   -> their gradients in the "backbone" bucket
+    all_reduce(backbone bucket, async); wait both
+    graph C: AdamW over all parameters (gradients = views of the buckets), step counter += 1
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, criterion, optimizer, x, y, mask=None, process_group=None, warmup=3):
+        if not (hasattr(model, "forward_backbone") and hasattr(model, "forward_temporal")):
+            raise TypeError("GraphedTrainStep drives a TransformerCNNHybrid")
+        if not hasattr(optimizer, "set_step_counter"):
+            raise TypeError("GraphedTrainStep needs HybridAdamW (its step number lives on the device)")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        dev = x.device
+        self.x, self.y = x.clone(), y.clone()                 # static inputs: copy new batches in with load()
+        self.mask = mask.clone() if mask is not None else None
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.t_params = [p for p in model.temporal_parameters() if p.requires_grad]
+        self.b_params = [p for p in model.backbone_parameters() if p.requires_grad]
+        if len(self.t_params) + len(self.b_params) != sum(1 for p in model.parameters() if p.requires_grad):
+            raise RuntimeError("model has trainable parameters outside its backbone and temporal parts")
+        self.t_bucket, self.t_views = self._bucket(self.t_params)
+        self.b_bucket, self.b_views = self._bucket(self.b_params)
+        self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
+        if self.world > 1:                                     # same start on every rank
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=0, group=process_group)
+
+        ops.set_step_counter(self.counter)
+        optimizer.set_step_counter(self.counter)
+        for p, v in zip(self.t_params + self.b_params, self.t_views + self.b_views):
+            p.grad = v                                         # AdamW reads the (all-reduced) buckets in place
+        # warm-up on a side stream (lazy initialisation, allocator steady state), then capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._piece_a(); self._reduce_wait(self._reduce(self.t_bucket)); self._piece_b(); self._reduce_wait(self._reduce(self.b_bucket))
+                self._piece_c()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._warm_steps = max(1, warmup)
+        self.ga, self.gb, self.gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.ga):
+            self._piece_a()
+        with torch.cuda.graph(self.gb, pool=self.ga.pool()):
+            self._piece_b()
+        with torch.cuda.graph(self.gc_, pool=self.ga.pool()):
+            self._piece_c()
+        # the captures above did not execute: the state is still "after the warm-up steps"
+
+    @staticmethod
+    def _bucket(params):
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(max(total, 1), dtype=torch.float32, device=params[0].device if params else "cuda")
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return flat, views
+
+    # ---- the three pieces (identical code runs eagerly in the warm-up and under capture) -------------------------------
+    def _piece_a(self):
+        h, B = self.model.forward_backbone(self.x)
+        logits = self.model.forward_temporal(h, B, self.mask)
+        loss = self.criterion(logits, self.y)
+        grads = torch.autograd.grad(loss, [h] + self.t_params)
+        self._h, self._gh = h, grads[0]
+        torch._foreach_copy_(self.t_views, list(grads[1:]))
+        self.loss = loss.detach()
+
+    def _piece_b(self):
+        grads = torch.autograd.grad(self._h, self.b_params, grad_outputs=self._gh)
+        torch._foreach_copy_(self.b_views, list(grads))
+        self._h = self._gh = None
+
+    def _piece_c(self):
+        if self.world > 1 and not self._avg:
+            self.t_bucket.mul_(1.0 / self.world)
+            self.b_bucket.mul_(1.0 / self.world)
+        self.optimizer.step()
+        self.counter.add_(1)
+
+    def _reduce(self, bucket):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(bucket, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _reduce_wait(work):
+        if work is not None:
+            work.wait()
+
+    # ---- public ---------------------------------------------------------------------------------------------------------
+    def load(self, x, y, mask=None):
+        """Copy the next batch into the static input buffers (same shapes as at construction)."""
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        if mask is not None:
+            self.mask.copy_(mask, non_blocking=True)
+
+    def step(self):
+        """One training step; returns the (device) loss tensor of this step -- reading it synchronises."""
+        self.ga.replay()
+        w1 = self._reduce(self.t_bucket)                       # rides under graph B
+        self.gb.replay()
+        w2 = self._reduce(self.b_bucket)
+        self._reduce_wait(w1)
+        self._reduce_wait(w2)
+        self.gc_.replay()
+        return self.loss
+
+    def fwd_bwd(self):
+        """Forward + loss + backward (+ all-reduce) only: no optimizer, the step counter does not advance."""
+        self.ga.replay()
+        w1 = self._reduce(self.t_bucket)
+        self.gb.replay()
+        w2 = self._reduce(self.b_bucket)
+        self._reduce_wait(w1)
+        self._reduce_wait(w2)
+        return self.loss
+
+    def eager_fwd_bwd(self):
+        """The same forward + backward issued launch by launch (for per-kernel event timing, which needs live launches)."""
+        self._piece_a()
+        self._piece_b()
+        return self.loss
+
+    def steps_done(self):
+        """Steps taken through this object, warm-up included (reads the device counter: synchronises)."""
+        return int(self.counter.item())
+
+    def sync_optimizer_state(self):
+        """Fold the device step counter into the optimizer's Python-side state (before state_dict())."""
+        n = self.steps_done()
+        for st in self.optimizer.state.values():
+            if "step" in st:
+                st["step"] = int(st["step"]) + n
+        self.counter.zero_()
+
+    def close(self):
+        ops.set_step_counter(None)
+        self.optimizer.set_step_counter(None)

@@ -163,7 +163,18 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         self._dt = ops.dtype_code(compute_dtype)
         self.fuse_model_ops = True        # hybrid::backbone + hybrid::temporal (one C call each way) instead of one operator per stage
 
-    def forward(self, x, mask=None):
+    def _fused(self):
+        """hybrid::backbone / hybrid::temporal apply when the model has the plain reference structure."""
+        stages = [getattr(self, f"encoder{i + 1}") for i in range(self.num_stages)]
+        bn0 = getattr(stages[0], stages[0]._norm)
+        return (self.fuse_model_ops and self.in_channels <= 4 and self.encoder.num_layers > 0 and self.token_proj.bias is not None
+                and self.head.bias is not None
+                and all(getattr(s, s._norm).track_running_stats and getattr(s, s._norm).running_mean is not None
+                        and getattr(s, s._norm).momentum == bn0.momentum and getattr(s, s._norm).eps == bn0.eps
+                        and s.training == self.training for s in stages))
+
+    def forward_backbone(self, x):
+        """Clips [B,T,C,H,W] (or frames [B,C,H,W] => T=1) -> (last pooled map, NHWC compute dtype [B*T, H/2^S, W/2^S, Cp], B)."""
         if x.dim() == 4:
             x = x.unsqueeze(1)
         if x.dim() != 5:
@@ -174,26 +185,35 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         B, T = x.shape[:2]
         f = x.reshape(B * T, *x.shape[2:]).float()                  # frames folded into the batch axis
         stages = [getattr(self, f"encoder{i + 1}") for i in range(self.num_stages)]
-        enc = self.encoder
-        fused = (self.fuse_model_ops and self.in_channels <= 4 and enc.num_layers > 0 and self.token_proj.bias is not None and self.head.bias is not None
-                 and all(getattr(s, s._norm).track_running_stats and getattr(s, s._norm).running_mean is not None
-                         and getattr(s, s._norm).momentum == getattr(stages[0], stages[0]._norm).momentum
-                         and getattr(s, s._norm).eps == getattr(stages[0], stages[0]._norm).eps
-                         and s.training == self.training for s in stages))
-        if fused:
-            # two model-level operators (hybrid::backbone, hybrid::temporal): the same kernels as the stage operators below, chained in C
-            h = ops.backbone(f, [(getattr(s, s._conv).weight, getattr(s, s._norm)) for s in stages], self.training, self._dt)
-            attn_p = enc.attention_layers[0]._attn_p()
-            return ops.temporal(h, self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias, mask, B,
-                                self._dt, enc.hidden_dim, enc.num_layers, enc.num_heads, attn_p, float(enc.dropout), ops.next_seed())
+        if self._fused():
+            # model-level operator: the same kernels as the stage operators below, chained in C (one call)
+            return ops.backbone(f, [(getattr(s, s._conv).weight, getattr(s, s._norm)) for s in stages], self.training, self._dt), B
         commit = []                                                  # running-statistics write-back of all stages: one multi-tensor copy
         if self.in_channels <= 4:
             h = self.encoder1.forward_nhwc(f, True, commit)
         else:
             h = self.encoder1.forward_nhwc(ops.nchw_to_nhwc(f, self._dt, ops.pad_channels(self.in_channels)), False, commit)
         for i in range(1, self.num_stages):
-            h = getattr(self, f"encoder{i + 1}").forward_nhwc(h, False, commit)
+            h = stages[i].forward_nhwc(h, False, commit)
         ops.commit_running_stats(commit)
-        tok = ops.token(h, self.token_proj.weight, self.token_proj.bias, self._dt).reshape(B, T, -1)
-        enc = self.encoder.forward_compute(tok, mask)
-        return ops.head(enc, self.head.weight, self.head.bias, self._dt)
+        return h, B
+
+    def forward_temporal(self, h, B, mask=None):
+        """Last pooled map -> frame tokens -> temporal encoder -> head: logits [B, num_classes]."""
+        enc = self.encoder
+        if self._fused():
+            return ops.temporal(h, self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias, mask, B,
+                                self._dt, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
+                                ops.next_seed())
+        tok = ops.token(h, self.token_proj.weight, self.token_proj.bias, self._dt).reshape(B, h.shape[0] // B, -1)
+        return ops.head(enc.forward_compute(tok, mask), self.head.weight, self.head.bias, self._dt)
+
+    def backbone_parameters(self):
+        return [p for i in range(self.num_stages) for p in getattr(self, f"encoder{i + 1}").parameters()]
+
+    def temporal_parameters(self):
+        return list(self.token_proj.parameters()) + list(self.encoder.parameters()) + list(self.head.parameters())
+
+    def forward(self, x, mask=None):
+        h, B = self.forward_backbone(x)
+        return self.forward_temporal(h, B, mask)

@@ -103,6 +103,22 @@ def next_seed():
             & _SEED_MASK)
 
 
+_STEP_COUNTER = [None]
+
+
+def set_step_counter(counter):
+    """Register (or clear, with None) the DEVICE step counter (int64 [1]) that stochastic kernels add to their by-value dropout
+    seed when they run.  Replayed hipGraphs (graph.GraphedTrainStep) re-issue the captured launches with the captured seed;
+    advancing this counter once per replay gives every step its own masks.  Eager runs leave it unset."""
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise ValueError("the step counter must be a cuda int64 tensor with one element")
+    _STEP_COUNTER[0] = counter
+
+
+def step_counter():
+    return _STEP_COUNTER[0]
+
+
 def _opt_ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -390,7 +406,7 @@ def _check_attention_limits(S, D, H):
 
 
 def encoder_op(x: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], dt: int, hid: int, L: int, H: int, attn_p: float,
-               layer_p: float, seed: int) -> Tuple[Tensor, Tensor]:
+               layer_p: float, seed: int, seed_inc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """x [B,S,D] T, mask fp32 [B,S,S] or None, params = L*14 fp32 tensors (order: include/hybrid_hip.h) -> (out, saved blob)."""
     _require_cuda(x, *params)
     x = x.contiguous()
@@ -401,18 +417,18 @@ def encoder_op(x: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], dt: 
     saved = _ws(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), dev)
     out = torch.empty(B, S, D, dtype=_TORCH_DTYPE[dt], device=dev)
     lib.call("hyb_encoder_fwd", dt, x.data_ptr(), _opt_ptr(mask), ptr_array([p.data_ptr() for p in ps]), out.data_ptr(), saved.data_ptr(),
-             B, S, D, hid, L, H, float(attn_p), float(layer_p), seed, _stream())
+             B, S, D, hid, L, H, float(attn_p), float(layer_p), seed, _opt_ptr(seed_inc), _stream())
     return out, saved
 
 
-def encoder_fake(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
+def encoder_fake(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     B, S, D = x.shape
     return torch.empty_like(x, memory_format=torch.contiguous_format), x.new_empty((max(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), 256),),
                                                                                     dtype=torch.uint8)
 
 
 def encoder_bwd_op(dout: Tensor, mask: Optional[Tensor], params: Sequence[Tensor], saved: Tensor, dt: int, hid: int, L: int, H: int,
-                   attn_p: float, layer_p: float, seed: int) -> List[Tensor]:
+                   attn_p: float, layer_p: float, seed: int, seed_inc: Optional[Tensor] = None) -> List[Tensor]:
     """-> [dx, dparam_0, ..., dparam_{14L-1}]"""
     _require_cuda(dout, saved)
     dout = dout.contiguous()
@@ -424,11 +440,11 @@ def encoder_bwd_op(dout: Tensor, mask: Optional[Tensor], params: Sequence[Tensor
     ws = _ws(_query("hyb_encoder_workspace_bytes", dt, B, S, D, hid, L, H), dev)
     lib.call("hyb_encoder_bwd", dt, dout.data_ptr(), _opt_ptr(mask), ptr_array([p.data_ptr() for p in ps]),
              ptr_array([g.data_ptr() for g in grads]), saved.data_ptr(), dx.data_ptr(), B, S, D, hid, L, H, float(attn_p),
-             float(layer_p), seed, ws.data_ptr(), ws.numel(), _stream())
+             float(layer_p), seed, _opt_ptr(seed_inc), ws.data_ptr(), ws.numel(), _stream())
     return [dx] + grads
 
 
-def encoder_bwd_fake(dout, mask, params, saved, dt, hid, L, H, attn_p, layer_p, seed):
+def encoder_bwd_fake(dout, mask, params, saved, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     return [torch.empty_like(dout, memory_format=torch.contiguous_format)] + [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
 
 
@@ -438,7 +454,8 @@ def encoder_bwd_fake(dout, mask, params, saved, dt, hid, L, H, attn_p, layer_p, 
 
 def encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed):
     B, S, _ = x.shape
-    return torch.ops.hybrid.encoder(x, check_mask(mask, B, S, x.device), list(params), dt, hid, L, H, float(attn_p), float(layer_p), seed)[0]
+    return torch.ops.hybrid.encoder(x, check_mask(mask, B, S, x.device), list(params), dt, hid, L, H, float(attn_p), float(layer_p), seed,
+                                    step_counter())[0]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -729,7 +746,8 @@ def backbone(x, stages, training, dt):
 
 
 def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, head_b: Tensor, mask: Optional[Tensor],
-                B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int,
+                seed_inc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """h [B*S, Hh, Ww, Cp] T (last pooled map) -> (logits [B, classes] fp32, feat, enc_saved, enc_out); the last three are saved for backward."""
     _require_cuda(h, token_w, head_w, *enc_params)
     h = h.contiguous()
@@ -747,11 +765,12 @@ def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequenc
     ps = [p.contiguous() for p in enc_params]
     lib.call("hyb_temporal_fwd", dt, h.data_ptr(), token_w.contiguous().data_ptr(), token_b.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
              head_w.contiguous().data_ptr(), head_b.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), tok.data_ptr(), saved.data_ptr(),
-             enc_out.data_ptr(), logits.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes, float(attn_p), float(layer_p), seed, _stream())
+             enc_out.data_ptr(), logits.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes, float(attn_p), float(layer_p), seed,
+             _opt_ptr(seed_inc), _stream())
     return logits, feat, saved, enc_out
 
 
-def temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
+def temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     N, Hh, Ww, Cp = h.shape
     S, D = N // B, token_w.shape[0]
     tdt = _TORCH_DTYPE[dt]
@@ -761,7 +780,7 @@ def temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, 
 
 def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, mask: Optional[Tensor], feat: Tensor,
                     saved: Tensor, enc_out: Tensor, Hh: int, Ww: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float,
-                    seed: int) -> List[Tensor]:
+                    seed: int, seed_inc: Optional[Tensor] = None) -> List[Tensor]:
     """-> [dh, dtoken_w, dtoken_b, dhead_w, dhead_b, denc_param_0, ...]"""
     _require_cuda(dlogits, feat)
     B, S, D = enc_out.shape
@@ -781,11 +800,11 @@ def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tenso
     lib.call("hyb_temporal_bwd", dt, dlogits.data_ptr(), token_w.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
              head_w.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), saved.data_ptr(), enc_out.data_ptr(), dtw.data_ptr(), dtb.data_ptr(),
              ptr_array([g.data_ptr() for g in grads]), dhw.data_ptr(), dhb.data_ptr(), dh.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes,
-             float(attn_p), float(layer_p), seed, ws.data_ptr(), ws.numel(), _stream())
+             float(attn_p), float(layer_p), seed, _opt_ptr(seed_inc), ws.data_ptr(), ws.numel(), _stream())
     return [dh, dtw, dtb, dhw, dhb] + grads
 
 
-def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed):
+def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     N, Cp = feat.shape
     c = lambda t: torch.empty_like(t, memory_format=torch.contiguous_format)
     return [feat.new_empty((N, Hh, Ww, Cp)), c(token_w), feat.new_empty((token_w.shape[0],), dtype=torch.float32), c(head_w),
@@ -799,7 +818,7 @@ def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, e
 def temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
     S = h.shape[0] // B
     return torch.ops.hybrid.temporal(h, token_w, token_b, list(enc_params), head_w, head_b, check_mask(mask, B, S, h.device), B, dt, hid, L, H,
-                                     float(attn_p), float(layer_p), seed)[0]
+                                     float(attn_p), float(layer_p), seed, step_counter())[0]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -887,10 +906,11 @@ class _TokenFn(torch.autograd.Function):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, dt, hid, L, H, attn_p, layer_p, seed, *params):
+    def forward(ctx, x, mask, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *params):
         with _below_autograd():
-            out, saved = torch.ops.hybrid.encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed)
+            out, saved = torch.ops.hybrid.encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed, seed_inc)
         ctx.save_for_backward(saved, *params) if mask is None else ctx.save_for_backward(saved, mask, *params)
+        ctx.seed_inc = seed_inc                     # an int64 counter, not part of the autograd graph
         ctx.cfg = (mask is not None, dt, hid, L, H, attn_p, layer_p, seed)
         ctx.mark_non_differentiable(saved)
         return out, saved
@@ -900,8 +920,8 @@ class _EncoderFn(torch.autograd.Function):
         has_mask, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
         saved, *rest = ctx.saved_tensors
         mask = rest.pop(0) if has_mask else None
-        res = torch.ops.hybrid.encoder_bwd(dout, mask, rest, saved, dt, hid, L, H, attn_p, layer_p, seed)
-        return (res[0],) + (None,) * 8 + tuple(res[1:])
+        res = torch.ops.hybrid.encoder_bwd(dout, mask, rest, saved, dt, hid, L, H, attn_p, layer_p, seed, ctx.seed_inc)
+        return (res[0],) + (None,) * 9 + tuple(res[1:])
 
 
 class _MhaFn(torch.autograd.Function):
@@ -982,10 +1002,11 @@ class _BackboneFn(torch.autograd.Function):
 
 class _TemporalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, token_w, token_b, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, *enc_params):
+    def forward(ctx, h, token_w, token_b, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *enc_params):
         with _below_autograd():
             logits, feat, saved, enc_out = torch.ops.hybrid.temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H,
-                                                                      attn_p, layer_p, seed)
+                                                                      attn_p, layer_p, seed, seed_inc)
+        ctx.seed_inc = seed_inc
         if mask is None:
             ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, *enc_params)
         else:
@@ -999,8 +1020,9 @@ class _TemporalFn(torch.autograd.Function):
         has_mask, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
         token_w, head_w, feat, saved, enc_out, *rest = ctx.saved_tensors
         mask = rest.pop(0) if has_mask else None
-        g = torch.ops.hybrid.temporal_bwd(dlogits, token_w, rest, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed)
-        return (g[0], g[1], g[2], g[3], g[4]) + (None,) * 9 + tuple(g[5:])
+        g = torch.ops.hybrid.temporal_bwd(dlogits, token_w, rest, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed,
+                                          ctx.seed_inc)
+        return (g[0], g[1], g[2], g[3], g[4]) + (None,) * 10 + tuple(g[5:])
 
 
 _define("nchw_to_nhwc", "(Tensor x, int dt, int cp) -> Tensor", nchw_to_nhwc_op, nchw_to_nhwc_fake, _NchwToNhwcFn.apply)
@@ -1013,11 +1035,12 @@ _define("convstage_bwd", "(Tensor dpooled, Tensor x, Tensor y_raw, Tensor weight
 _define("token", "(Tensor x, Tensor weight, Tensor? bias, int dt) -> (Tensor, Tensor)", token_op, token_fake, _TokenFn.apply)
 _define("token_bwd", "(Tensor dtok, Tensor feat, Tensor weight, int Hh, int Ww, bool has_bias, int dt) -> (Tensor, Tensor, Tensor)", token_bwd_op,
         token_bwd_fake)
-_define("encoder", "(Tensor x, Tensor? mask, Tensor[] params, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed) -> (Tensor, Tensor)",
-        encoder_op, encoder_fake,
-        lambda x, mask, params, dt, hid, L, H, attn_p, layer_p, seed: _EncoderFn.apply(x, mask, dt, hid, L, H, attn_p, layer_p, seed, *params))
+_define("encoder", "(Tensor x, Tensor? mask, Tensor[] params, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, "
+        "Tensor? seed_inc=None) -> (Tensor, Tensor)", encoder_op, encoder_fake,
+        lambda x, mask, params, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None: _EncoderFn.apply(x, mask, dt, hid, L, H, attn_p, layer_p, seed,
+                                                                                                    seed_inc, *params))
 _define("encoder_bwd", "(Tensor dout, Tensor? mask, Tensor[] params, Tensor saved, int dt, int hid, int L, int H, float attn_p, float layer_p, "
-        "int seed) -> Tensor[]", encoder_bwd_op, encoder_bwd_fake)
+        "int seed, Tensor? seed_inc=None) -> Tensor[]", encoder_bwd_op, encoder_bwd_fake)
 _define("mha", "(Tensor q_in, Tensor k_in, Tensor v_in, Tensor? mask, Tensor[] params, int dt, int H, float p_drop, int seed) -> "
         "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", mha_op, mha_fake,
         lambda q, k, v, mask, params, dt, H, p_drop, seed: _MhaFn.apply(q, k, v, mask, dt, H, p_drop, seed, *params))
@@ -1034,9 +1057,10 @@ _define("backbone", "(Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] beta
 _define("backbone_bwd", "(Tensor dpooled, Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] saved, bool training, int dt) -> Tensor[]",
         backbone_bwd_op, backbone_bwd_fake)
 _define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_params, Tensor head_w, Tensor head_b, Tensor? mask, int B, int dt, "
-        "int hid, int L, int H, float attn_p, float layer_p, int seed) -> (Tensor, Tensor, Tensor, Tensor)", temporal_op, temporal_fake,
-        lambda h, tw, tb, ps, hw, hb, mask, B, dt, hid, L, H, attn_p, layer_p, seed: _TemporalFn.apply(h, tw, tb, hw, hb, mask, B, dt, hid, L, H,
-                                                                                                     attn_p, layer_p, seed, *ps))
+        "int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> (Tensor, Tensor, Tensor, Tensor)", temporal_op,
+        temporal_fake,
+        lambda h, tw, tb, ps, hw, hb, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None: _TemporalFn.apply(
+            h, tw, tb, hw, hb, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *ps))
 _define("temporal_bwd", "(Tensor dlogits, Tensor token_w, Tensor[] enc_params, Tensor head_w, Tensor? mask, Tensor feat, Tensor saved, "
-        "Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed) -> Tensor[]", temporal_bwd_op,
-        temporal_bwd_fake)
+        "Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> Tensor[]",
+        temporal_bwd_op, temporal_bwd_fake)

@@ -17,6 +17,12 @@ class HybridAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached pointer tables of the tensors whose addresses never change
+        self._step_counter = None    # device int64 [1]: the kernel uses step + counter (captured launches, graph.GraphedTrainStep)
+
+    def set_step_counter(self, counter):
+        """With a device counter the step number used by the kernel is state['step'] + counter, read on the device: one captured
+        launch then serves every replay of a hipGraph (the counter is advanced inside the graph)."""
+        self._step_counter = counter
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -51,8 +57,10 @@ class HybridAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-            steps = {int(self.state[p]["step"]) for p in ps}
+                if self._step_counter is None:
+                    st["step"] += 1
+            # with a device counter the Python-side step stays put and the kernel uses (step + 1) + counter
+            steps = {int(self.state[p]["step"]) + (1 if self._step_counter is not None else 0) for p in ps}
             if len(steps) != 1:
                 raise RuntimeError("HybridAdamW: parameters of one group must share the step count")
             # the cached pointer tables are valid only while every parameter AND both of its moment tensors stay where they are:
@@ -71,5 +79,6 @@ class HybridAdamW(torch.optim.Optimizer):
                 grads.append(g)
             b1, b2 = group["betas"]
             lib.call("hyb_adamw_step", len(ps), tab[2], ptr_array([g.data_ptr() for g in grads]), tab[3], tab[4], tab[5],
-                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(), _stream())
+                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(),
+                     self._step_counter.data_ptr() if self._step_counter is not None else None, _stream())
         return loss
