@@ -279,6 +279,45 @@ int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, cons
                      int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
                      const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- FCT, the reference's "Fully Convolutional Transformer" (FCT.py:24-254; SURVEY.md section 8f-1, first "next" row) -----------
+ * FORWARD entry points (the backward is the next step of this row).  Tensors are NHWC fp32 with the TRUE channel count
+ * ([N,H,W,C]; a pixel's channels are contiguous: the token view of the spatial attention, FCT.py:69-74, is free).  Arithmetic is
+ * exact fp32 (fp32-input MFMA for the contractions). */
+#define HYB_ACT_NONE 0
+#define HYB_ACT_RELU 1
+#define HYB_ACT_GELU 2    /* nn.GELU(): erf form, FCT.py:114 */
+#define HYB_ACT_SIGMOID 3 /* FCT.py:205 */
+/* y = act(conv3x3(x, w, stride 1, "same" zero padding, dilation) + b): nn.Conv2d(.., 3, 1, padding="same"[, dilation=d]) of
+ * FCT.py:140-143, 110-113, 172-174, 194-196 followed by the ReLU / GELU / Sigmoid the reference applies next.  w [Co,Ci,3,3], b [Co] or NULL. */
+size_t hyb_fct_conv_workspace(int N, int H, int W, int Ci, int Co);
+int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Ci, int Co, int dilation,
+                     int act, void* workspace, size_t workspace_bytes, void* stream);
+/* Attention._build_projection for q, k and v in one pass (FCT.py:41-57): depthwise Conv2d(C, C, 3, padding 1, groups=C) + bias
+ * -> ReLU -> LayerNorm over C.  HOST arrays of three device pointers each (q, k, v order): w [C,1,3,3], b [C] (or NULL), LayerNorm
+ * weight / bias [C].  C a power of two. */
+int hyb_fct_qkv_proj_fwd(const float* x, const float* const* w3, const float* const* b3, const float* const* g3, const float* const* beta3,
+                         float* q, float* k, float* v, int N, int H, int W, int C, float eps, void* stream);
+/* LayerNorm over C of P = N*H*W pixel rows (Transformer.layernorm, FCT.py:97-99) */
+int hyb_fct_ln_fwd(const float* x, const float* g, const float* b, float* y, long long P, int C, float eps, void* stream);
+/* nn.MultiheadAttention(embed_dim=C, num_heads, batch_first=True)(query=q, key=k, value=v, need_weights=False), FCT.py:37,75:
+ * q, k, v, out [N, L, C]; in_w [3C, C], in_b [3C] (or NULL), out_w [C, C], out_b [C] (or NULL); softmax scale 1/sqrt(C/heads);
+ * L = H*W tokens per image are streamed through an online softmax (nothing of size L x L is stored). */
+size_t hyb_fct_mha_workspace(int N, int L, int C, int heads);
+int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, const float* in_w, const float* in_b, const float* out_w,
+                    const float* out_b, float* out, int N, int L, int C, int heads, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* y = a + b (torch.add, FCT.py:96,101,127-128) */
+int hyb_fct_add(const float* a, const float* b, float* y, long long n, void* stream);
+/* mode 0: nn.MaxPool2d(2) (FCT.py:147), 1: nn.AvgPool2d(2,2) (FCT.py:222), 2: nn.Upsample(scale_factor=2) nearest (FCT.py:170).
+ * H, W are the input sizes; pooling floors odd sizes like torch. */
+int hyb_fct_resample(int mode, const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* torch.cat((a, b), dim=channels) (FCT.py:157,180) */
+int hyb_fct_concat(const float* a, int Ca, const float* b, int Cb, float* y, long long P, void* stream);
+/* DiceLoss.forward (Metrics.py:14-22) on channel 0 of NCHW pred / true [N,C,H,W]: 1 - (2 sum(p t) + smooth) / (sum p + sum t + smooth) */
+size_t hyb_dice_workspace(void);
+int hyb_dice_fwd(const float* pred, const float* tru, float* loss /* [1] */, int N, int C, long long HW, float smooth, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
  * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
  * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]

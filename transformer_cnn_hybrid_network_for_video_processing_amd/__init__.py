@@ -3,5 +3,6 @@ from .modules import (ConvBNReLUPool, HybridCrossEntropyLoss, MultiheadAttention
                       TransformerEncoder)
 from .optim import HybridAdamW  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
+from .fct import FCT, DiceLoss  # noqa: F401
 
-__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW", "GraphedTrainStep"]
+__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW", "GraphedTrainStep", "FCT", "DiceLoss"]

@@ -530,3 +530,136 @@ int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, cons
     if (dtype == HYB_BF16) return attn_bwd_t<bf16>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, seed_inc, st);
     return HYB_E_ARG;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Long-sequence forward (FCT's spatial attention: nn.MultiheadAttention over H*W = 1 024 .. 12 544 pixel tokens, FCT.py:37,75):
+// the same swapped-product structure with an ONLINE softmax over 64-key blocks.  A workgroup = 4 waves = 64 queries of one
+// (image, head); K and V blocks are staged in LDS once per block for all four waves.  Per lane the running max / sum belong to
+// ONE query (column p of the swapped product), so the rescale of the O^T accumulators is a per-lane scalar multiply.
+// q, k, v, out: [N*L][ld] with head h at features [h*dhp, (h+1)*dhp), dhp a multiple of 8 (narrower heads are zero-padded by the
+// caller: zero features change neither scores nor outputs).  No mask, no dropout (the reference passes neither).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8_c;
+
+template <typename T>
+__device__ __forceinline__ void lds_row_frag(Frag<T>& f, const T* img, int ldi, int row, int f0, int dhp) {
+    if (f0 < dhp) frag_load(f, img + row * ldi + f0);
+    else frag_zero(f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+                                                           int L, int H, int dhp, int ld, int ldi, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Kimg = reinterpret_cast<T*>(smem_raw);                  // [64][ldi]
+    T* Vimg = Kimg + 64 * ldi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * dhp;
+    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    const int query = blockIdx.x * 64 + wave * 16 + p;
+    const int qrow = query < L ? query : L - 1;
+    Frag<T> fq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < ks) {
+            const int f0 = s * 32 + 8 * g;
+            if (f0 < dhp) frag_load(fq[s], q + base + (long long)qrow * ld + f0); else frag_zero(fq[s]);
+        }
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[MAXDT];
+#pragma unroll
+    for (int dt = 0; dt < MAXDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < L; kb += 64) {
+        __syncthreads();                                       // every wave is done with the previous block's images
+        for (int u = tid; u < 64 * segs; u += 256) {
+            const int r = u / segs, c = (u - r * segs) * 8;
+            Vec8<T> a, b;
+            if (kb + r < L) { a.load(k + base + (long long)(kb + r) * ld + c); b.load(v + base + (long long)(kb + r) * ld + c); }
+            else { a.zero(); b.zero(); }
+            a.store(Kimg + r * ldi + c);
+            b.store(Vimg + r * ldi + c);
+        }
+        if ((dhp & 15) != 0)                                   // 8-wide tail of the last 16-feature tile: zero it (transposed reads touch it)
+            for (int u = tid; u < 64; u += 256) { Vec8<T> z; z.zero(); z.store(Vimg + u * ldi + dhp); }
+        __syncthreads();
+        f32x4 sT[4];
+        float mx = m;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ks) {
+                    Frag<T> a;
+                    lds_row_frag(a, Kimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
+                    sT[kt] = mma32(a, fq[s], sT[kt]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = (kb + kt * 16 + 4 * g + r < L) ? sT[kt][r] * scale : -INFINITY;
+                sT[kt][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+        mx = quad_lane_max(mx);                                // >= the previous m, finite (every block holds at least one real key)
+        const float alpha = __expf(m - mx);
+        float sum = 0.f;
+        Frag16<T> P[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pv[r] = __expf(sT[kt][r] - mx); sum += pv[r]; }
+            acc_to_frag(P[kt], pv);
+        }
+        l = l * alpha + quad_lane_sum(sum);
+        m = mx;
+#pragma unroll
+        for (int dt = 0; dt < MAXDT; ++dt)
+            if (dt < DT) {
+                f32x4 acc = o[dt] * alpha;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    Frag16<T> a;
+                    tr_read(a, Vimg, ldi, kt * 16, dt * 16, lane);
+                    acc = mma16(a, P[kt], acc);
+                }
+                o[dt] = acc;
+            }
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int dt = 0; dt < MAXDT; ++dt)
+        if (dt < DT) {
+            const int f0 = dt * 16 + 4 * g;
+            if (query < L && f0 < dhp) store4(out + base + (long long)query * ld + f0, o[dt] * inv);
+        }
+}
+
+}  // namespace
+
+// Internal (fct.hip): out = softmax(q k^T * scale) v per (image, head), L tokens, heads of padded width dhp at stride ld
+int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int N, int L, int H, int dhp, int ld, float scale,
+                            hipStream_t st) {
+    if (!q || !k || !v || !out || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 || dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535) return HYB_E_ARG;
+    const int es = dtype == HYB_F32 ? 4 : 2;
+    int bytes = ((dhp + 15) / 16) * 16 * es;
+    if ((bytes / 32) % 2 == 0) bytes += 32;
+    const int ldi = bytes / es;
+    const size_t lds = (size_t)2 * 64 * ldi * es;
+    const dim3 grid(hyb_cdiv(L, 64), N * H);
+    if (dtype == HYB_F32) {
+        if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)flash_fwd_kernel<float>, 160 * 1024)) return e; }
+        hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, L, H, dhp, ld, ldi, scale);
+    } else if (dtype == HYB_BF16) {
+        hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, L, H, dhp, ld, ldi, scale);
+    } else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}

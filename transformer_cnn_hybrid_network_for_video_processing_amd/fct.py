@@ -1,0 +1,172 @@
+"""Drop-in ``FCT`` (the reference's "Fully Convolutional Transformer", FCT.py:210-254) and ``DiceLoss`` (Metrics.py:5-22) on the
+MI355X HIP path -- SURVEY.md section 8f-1, the first "next" row.
+
+Contract kept from the reference harness (FCT.py:302,330,333): ``FCT()`` takes no arguments, ``model(x)`` maps ``[B,3,H,W]`` fp32
+(H = W a multiple of 32) to a sigmoid mask ``[B,1,H,W]``, ``DiceLoss()(y_pred, y_true)`` is a scalar, and the module / state-dict
+names are the reference's (``block_1.conv1_a.weight`` .. ``ds.conv3.bias``; the submodules below own the parameters under those
+names and are never called themselves), so checkpoints written by the reference harness (FCT.py:366-373) load unchanged.
+Clips are fed frame-folded, ``[B*T,3,H,W]`` (north_star: "folded over B*T").
+
+STATUS: forward (inference, ``.eval()``) on the GPU; the train-mode forward (dropout 0.3 / 0.1, FCT.py:115,146,175) and the
+backward are the next step of this row and raise until then.  There is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _conv(c, x, act, dilation=1):
+    return torch.ops.hybrid.fct_conv(x, c.weight, c.bias, dilation, act)
+
+
+class Attention(nn.Module):                                       # parameter names of FCT.py:24-39
+    def __init__(self, channels, num_heads, attention_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.conv_q = nn.Conv2d(channels, channels, 3, 1, 1, bias=attention_bias, groups=channels)
+        self.layernorm_q = nn.LayerNorm(channels, eps=1e-5)
+        self.conv_k = nn.Conv2d(channels, channels, 3, 1, 1, bias=attention_bias, groups=channels)
+        self.layernorm_k = nn.LayerNorm(channels, eps=1e-5)
+        self.conv_v = nn.Conv2d(channels, channels, 3, 1, 1, bias=attention_bias, groups=channels)
+        self.layernorm_v = nn.LayerNorm(channels, eps=1e-5)
+        self.attention = nn.MultiheadAttention(embed_dim=channels, bias=attention_bias, batch_first=True, num_heads=num_heads)
+
+    def forward(self, x):                                         # x NHWC; FCT.py:41-79 as two fused operators
+        N, H, W, C = x.shape
+        convs, lns = (self.conv_q, self.conv_k, self.conv_v), (self.layernorm_q, self.layernorm_k, self.layernorm_v)
+        q, k, v = torch.ops.hybrid.fct_qkv_proj(x, [c.weight for c in convs], [c.bias for c in convs], [l.weight for l in lns],
+                                                [l.bias for l in lns], lns[0].eps)
+        a = self.attention
+        out = torch.ops.hybrid.fct_mha(q.view(N, H * W, C), k.view(N, H * W, C), v.view(N, H * W, C), a.in_proj_weight, a.in_proj_bias,
+                                       a.out_proj.weight, a.out_proj.bias, self.num_heads)
+        return out.view(N, H, W, C)
+
+
+class Wide_Focus(nn.Module):                                      # FCT.py:107-115
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
+        self.conv2 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same", dilation=2)
+        self.conv3 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same", dilation=3)
+        self.conv4 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
+
+    def forward(self, x):                                         # FCT.py:117-132 (eval: dropout is the identity)
+        added = torch.ops.hybrid.fct_add(torch.ops.hybrid.fct_add(_conv(self.conv1, x, ops.ACT_GELU, 1), _conv(self.conv2, x, ops.ACT_GELU, 2)),
+                                         _conv(self.conv3, x, ops.ACT_GELU, 3))
+        return _conv(self.conv4, added, ops.ACT_GELU, 1)
+
+
+class Transformer(nn.Module):                                     # FCT.py:84-91
+    def __init__(self, in_channels, out_channels, num_heads):
+        super().__init__()
+        self.attention_output = Attention(in_channels, num_heads)
+        self.conv1 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
+        self.layernorm = nn.LayerNorm(out_channels, eps=1e-5)
+        self.wide_focus = Wide_Focus(out_channels, out_channels)
+
+    def forward(self, x):                                         # FCT.py:93-102
+        x2 = torch.ops.hybrid.fct_add(_conv(self.conv1, self.attention_output(x), ops.ACT_NONE), x)
+        x3 = torch.ops.hybrid.fct_ln(x2, self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
+        return torch.ops.hybrid.fct_add(x2, self.wide_focus(x3))
+
+
+class Block_encoder_bottleneck(nn.Module):                        # FCT.py:136-147
+    def __init__(self, blk, in_channels, out_channels, att_heads):
+        super().__init__()
+        self.blk = blk
+        self.conv1_a = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
+        self.conv1_b = nn.Conv2d(3, in_channels, 3, 1, padding="same")
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
+        self.conv3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
+        self.trans = Transformer(out_channels, out_channels, att_heads)
+
+    def forward(self, x, scale_img=None):                         # FCT.py:149-162
+        if self.blk in ("first", "bottleneck"):
+            x1 = _conv(self.conv2, _conv(self.conv1_a, x, ops.ACT_RELU), ops.ACT_RELU)
+        else:
+            x1 = torch.ops.hybrid.fct_concat(_conv(self.conv1_b, scale_img, ops.ACT_RELU), x)
+            x1 = _conv(self.conv3, _conv(self.conv2, x1, ops.ACT_RELU), ops.ACT_RELU)
+        return self.trans(torch.ops.hybrid.fct_resample(x1, 0))
+
+
+class Block_decoder(nn.Module):                                   # FCT.py:167-175
+    def __init__(self, in_channels, out_channels, att_heads):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
+        self.conv2 = nn.Conv2d(out_channels * 2, out_channels, 3, 1, padding="same")
+        self.conv3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
+        self.trans = Transformer(out_channels, out_channels, att_heads)
+
+    def forward(self, x, skip):                                   # FCT.py:177-186
+        x1 = _conv(self.conv1, torch.ops.hybrid.fct_resample(x, 2), ops.ACT_RELU)
+        x1 = torch.ops.hybrid.fct_concat(skip, x1)
+        return self.trans(_conv(self.conv3, _conv(self.conv2, x1, ops.ACT_RELU), ops.ACT_RELU))
+
+
+class DS_out(nn.Module):                                          # FCT.py:191-198
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, in_channels, 3, 1, padding="same")
+        self.conv2 = nn.Conv2d(in_channels, in_channels, 3, 1, padding="same")
+        self.conv3 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
+
+    def forward(self, x):                                         # FCT.py:200-206
+        x1 = _conv(self.conv2, _conv(self.conv1, torch.ops.hybrid.fct_resample(x, 2), ops.ACT_RELU), ops.ACT_RELU)
+        return _conv(self.conv3, x1, ops.ACT_SIGMOID)
+
+
+class FCT(nn.Module):
+    """``FCT()``: zero-argument constructor like the reference (FCT.py:211-233: 2 heads, filters 8-16-32-64-128-64-32-16-8)."""
+
+    def __init__(self):
+        super().__init__()
+        f, h = (8, 16, 32, 64, 128, 64, 32, 16, 8), 2
+        self.block_1 = Block_encoder_bottleneck("first", 3, f[0], h)
+        self.block_2 = Block_encoder_bottleneck("second", f[0], f[1], h)
+        self.block_3 = Block_encoder_bottleneck("third", f[1], f[2], h)
+        self.block_4 = Block_encoder_bottleneck("fourth", f[2], f[3], h)
+        self.block_5 = Block_encoder_bottleneck("bottleneck", f[3], f[4], h)
+        self.block_6 = Block_decoder(f[4], f[5], h)
+        self.block_7 = Block_decoder(f[5], f[6], h)
+        self.block_8 = Block_decoder(f[6], f[7], h)
+        self.block_9 = Block_decoder(f[7], f[8], h)
+        self.ds = DS_out(f[8], 1)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected frames [B,3,H,W] (clips folded over B*T)")
+        if not x.is_cuda:
+            raise RuntimeError("FCT runs on the MI355X HIP path only: move the model and input to 'cuda' (there is no CPU fallback)")
+        if x.shape[2] % 32 != 0 or x.shape[3] != x.shape[2]:
+            # the reference fails at its skip concat (FCT.py:181) / its square-map view (FCT.py:77) for any other size
+            raise RuntimeError(f"FCT needs square inputs with H = W a multiple of 32 (got {tuple(x.shape[2:])})")
+        if self.training:
+            raise NotImplementedError("FCT on the HIP path is forward-only so far: call .eval() (train-mode dropout and the backward are "
+                                      "the next step of SURVEY.md section 8f-1)")
+        B, _, H, W = x.shape
+        x = ops.nchw_to_nhwc(x, ops.HYB_F32, 3)                                   # NHWC fp32, 3 channels
+        s2 = torch.ops.hybrid.fct_resample(x, 1)                                  # multi-scale input pyramid, FCT.py:238-240
+        s3 = torch.ops.hybrid.fct_resample(s2, 1)
+        s4 = torch.ops.hybrid.fct_resample(s3, 1)
+        x1 = self.block_1(x)
+        x2 = self.block_2(x1, s2)
+        x3 = self.block_3(x2, s3)
+        x4 = self.block_4(x3, s4)
+        y = self.block_5(x4)
+        y = self.block_6(y, x4)
+        y = self.block_7(y, x3)
+        y = self.block_8(y, x2)
+        y = self.block_9(y, x1)
+        return ops.nhwc_to_nchw(self.ds(y), ops.HYB_F32, 1)                       # [B,1,H,W]
+
+
+class DiceLoss(nn.Module):
+    """Metrics.py:5-22 (``num_classes`` is accepted and unused there too)."""
+
+    def __init__(self, num_classes=8):
+        super().__init__()
+        self.smooth = 1.0
+
+    def forward(self, y_pred, y_true):
+        return torch.ops.hybrid.dice_loss(y_pred, y_true, self.smooth)

@@ -1064,3 +1064,152 @@ _define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_par
 _define("temporal_bwd", "(Tensor dlogits, Tensor token_w, Tensor[] enc_params, Tensor head_w, Tensor? mask, Tensor feat, Tensor saved, "
         "Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> Tensor[]",
         temporal_bwd_op, temporal_bwd_fake)
+
+
+# ---------------------------------------------------------------------------------------------
+# FCT forward operators (FCT.py:24-254).  NHWC fp32 tensors with the true channel count.  Forward only:
+# no Autograd kernel is registered, so a backward through them fails loudly ("no autograd formula was registered").
+# ---------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+def fct_conv_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dilation: int, act: int) -> Tensor:
+    _require_cuda(x, weight)
+    x = _f32c(x)
+    N, H, W, Ci = x.shape
+    Co = weight.shape[0]
+    y = torch.empty(N, H, W, Co, dtype=torch.float32, device=x.device)
+    ws = _ws(_query("hyb_fct_conv_workspace", N, H, W, Ci, Co), x.device)
+    lib.call("hyb_fct_conv_fwd", x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr() if bias is not None else None, y.data_ptr(),
+             N, H, W, Ci, Co, dilation, act, ws.data_ptr(), ws.numel(), _stream())
+    return y
+
+
+def fct_conv_fake(x, weight, bias, dilation, act):
+    N, H, W, _ = x.shape
+    return x.new_empty((N, H, W, weight.shape[0]), dtype=torch.float32)
+
+
+def fct_qkv_proj_op(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor], ln_weights: Sequence[Tensor], ln_biases: Sequence[Tensor],
+                    eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    _require_cuda(x, *weights)
+    x = _f32c(x)
+    N, H, W, C = x.shape
+    q, k, v = (torch.empty_like(x) for _ in range(3))
+    ws_, bs_, gs_, be_ = ([_f32c(t) for t in lst] for lst in (weights, biases, ln_weights, ln_biases))
+    lib.call("hyb_fct_qkv_proj_fwd", x.data_ptr(), ptr_array([t.data_ptr() for t in ws_]), ptr_array([t.data_ptr() for t in bs_]),
+             ptr_array([t.data_ptr() for t in gs_]), ptr_array([t.data_ptr() for t in be_]), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+             N, H, W, C, float(eps), _stream())
+    return q, k, v
+
+
+def fct_qkv_proj_fake(x, weights, biases, ln_weights, ln_biases, eps):
+    e = lambda: x.new_empty(x.shape, dtype=torch.float32)
+    return e(), e(), e()
+
+
+def fct_ln_op(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    _require_cuda(x, weight)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    lib.call("hyb_fct_ln_fwd", x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr(), y.data_ptr(), x.numel() // C, C, float(eps), _stream())
+    return y
+
+
+def fct_ln_fake(x, weight, bias, eps):
+    return x.new_empty(x.shape, dtype=torch.float32)
+
+
+def fct_mha_op(q: Tensor, k: Tensor, v: Tensor, in_w: Tensor, in_b: Optional[Tensor], out_w: Tensor, out_b: Optional[Tensor], heads: int) -> Tensor:
+    """q, k, v [N, L, C] (pixel tokens) -> nn.MultiheadAttention output [N, L, C]."""
+    _require_cuda(q, in_w)
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    N, L, C = q.shape
+    out = torch.empty_like(q)
+    ws = _ws(_query("hyb_fct_mha_workspace", N, L, C, heads), q.device)
+    lib.call("hyb_fct_mha_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _f32c(in_w).data_ptr(), _f32c(in_b).data_ptr() if in_b is not None else None,
+             _f32c(out_w).data_ptr(), _f32c(out_b).data_ptr() if out_b is not None else None, out.data_ptr(), N, L, C, heads, ws.data_ptr(), ws.numel(),
+             _stream())
+    return out
+
+
+def fct_mha_fake(q, k, v, in_w, in_b, out_w, out_b, heads):
+    return q.new_empty(q.shape, dtype=torch.float32)
+
+
+def fct_add_op(a: Tensor, b: Tensor) -> Tensor:
+    _require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    if a.shape != b.shape:
+        raise RuntimeError(f"shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    y = torch.empty_like(a)
+    lib.call("hyb_fct_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream())
+    return y
+
+
+def fct_add_fake(a, b):
+    return a.new_empty(a.shape, dtype=torch.float32)
+
+
+def fct_resample_op(x: Tensor, mode: int) -> Tensor:
+    """mode 0 MaxPool2d(2), 1 AvgPool2d(2,2), 2 nearest Upsample x2; NHWC."""
+    _require_cuda(x)
+    x = _f32c(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C) if mode == 2 else (N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    lib.call("hyb_fct_resample", mode, x.data_ptr(), y.data_ptr(), N, H, W, C, _stream())
+    return y
+
+
+def fct_resample_fake(x, mode):
+    N, H, W, C = x.shape
+    return x.new_empty((N, 2 * H, 2 * W, C) if mode == 2 else (N, H // 2, W // 2, C), dtype=torch.float32)
+
+
+def fct_concat_op(a: Tensor, b: Tensor) -> Tensor:
+    _require_cuda(a, b)
+    a, b = _f32c(a), _f32c(b)
+    if a.shape[:-1] != b.shape[:-1]:
+        raise RuntimeError(f"Sizes of tensors must match except in the channel dimension: {tuple(a.shape)} vs {tuple(b.shape)}")
+    y = torch.empty(*a.shape[:-1], a.shape[-1] + b.shape[-1], dtype=torch.float32, device=a.device)
+    lib.call("hyb_fct_concat", a.data_ptr(), a.shape[-1], b.data_ptr(), b.shape[-1], y.data_ptr(), a.numel() // a.shape[-1], _stream())
+    return y
+
+
+def fct_concat_fake(a, b):
+    return a.new_empty((*a.shape[:-1], a.shape[-1] + b.shape[-1]), dtype=torch.float32)
+
+
+def dice_loss_op(pred: Tensor, true: Tensor, smooth: float) -> Tensor:
+    """DiceLoss (Metrics.py:5-22) on channel 0 of NCHW tensors."""
+    _require_cuda(pred, true)
+    if pred.shape != true.shape:
+        raise AssertionError("y_pred and y_true sizes differ")          # the reference asserts (Metrics.py:15)
+    pred, true = _f32c(pred), _f32c(true)
+    N, C = pred.shape[0], pred.shape[1]
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = _ws(_query("hyb_dice_workspace"), pred.device)
+    lib.call("hyb_dice_fwd", pred.data_ptr(), true.data_ptr(), loss.data_ptr(), N, C, pred.numel() // (N * C), float(smooth), ws.data_ptr(),
+             ws.numel(), _stream())
+    return loss
+
+
+def dice_loss_fake(pred, true, smooth):
+    return pred.new_empty((), dtype=torch.float32)
+
+
+_define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> Tensor", fct_conv_op, fct_conv_fake)
+_define("fct_qkv_proj", "(Tensor x, Tensor[] weights, Tensor[] biases, Tensor[] ln_weights, Tensor[] ln_biases, float eps) -> (Tensor, Tensor, Tensor)",
+        fct_qkv_proj_op, fct_qkv_proj_fake)
+_define("fct_ln", "(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", fct_ln_op, fct_ln_fake)
+_define("fct_mha", "(Tensor q, Tensor k, Tensor v, Tensor in_w, Tensor? in_b, Tensor out_w, Tensor? out_b, int heads) -> Tensor", fct_mha_op,
+        fct_mha_fake)
+_define("fct_add", "(Tensor a, Tensor b) -> Tensor", fct_add_op, fct_add_fake)
+_define("fct_resample", "(Tensor x, int mode) -> Tensor", fct_resample_op, fct_resample_fake)
+_define("fct_concat", "(Tensor a, Tensor b) -> Tensor", fct_concat_op, fct_concat_fake)
+_define("dice_loss", "(Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_op, dice_loss_fake)
