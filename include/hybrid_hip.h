@@ -280,7 +280,7 @@ int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, cons
                      const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- FCT, the reference's "Fully Convolutional Transformer" (FCT.py:24-254; SURVEY.md section 8f-1, first "next" row) -----------
- * FORWARD entry points (the backward is the next step of this row).  Tensors are NHWC fp32 with the TRUE channel count
+ * FORWARD entry points (the backward is the next step of this row).  Arrays are NHWC fp32 with the TRUE channel count
  * ([N,H,W,C]; a pixel's channels are contiguous: the token view of the spatial attention, FCT.py:69-74, is free).  Arithmetic is
  * exact fp32 (fp32-input MFMA for the contractions). */
 #define HYB_ACT_NONE 0

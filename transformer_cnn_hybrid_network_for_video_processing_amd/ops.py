@@ -1203,13 +1203,46 @@ def dice_loss_fake(pred, true, smooth):
     return pred.new_empty((), dtype=torch.float32)
 
 
-_define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> Tensor", fct_conv_op, fct_conv_fake)
+class _ForwardOnlyFn(torch.autograd.Function):
+    """Autograd-key kernel of the forward-only FCT operators: the forward runs; a backward through it raises instead of passing
+    silently (torch's default for an operator without an autograd formula is a warning)."""
+
+    @staticmethod
+    def forward(ctx, name, nlists, *flat):
+        args, i = [], 0
+        for n in nlists:                                       # re-nest the tensor-list arguments (n < 0: a single argument)
+            if n < 0:
+                args.append(flat[i]); i += 1
+            else:
+                args.append(list(flat[i:i + n])); i += n
+        ctx.name = name
+        with _below_autograd():
+            return getattr(torch.ops.hybrid, name)(*args)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(f"hybrid::{ctx.name} is forward-only so far: the FCT backward is the next step of SURVEY.md section 8f-1")
+
+
+def _forward_only(name):
+    def kernel(*args):
+        nlists, flat = [], []
+        for a in args:
+            if isinstance(a, (list, tuple)):
+                nlists.append(len(a)); flat += list(a)
+            else:
+                nlists.append(-1); flat.append(a)
+        return _ForwardOnlyFn.apply(name, tuple(nlists), *flat)
+    return kernel
+
+
+_define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> Tensor", fct_conv_op, fct_conv_fake, _forward_only("fct_conv"))
 _define("fct_qkv_proj", "(Tensor x, Tensor[] weights, Tensor[] biases, Tensor[] ln_weights, Tensor[] ln_biases, float eps) -> (Tensor, Tensor, Tensor)",
-        fct_qkv_proj_op, fct_qkv_proj_fake)
-_define("fct_ln", "(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", fct_ln_op, fct_ln_fake)
+        fct_qkv_proj_op, fct_qkv_proj_fake, _forward_only("fct_qkv_proj"))
+_define("fct_ln", "(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", fct_ln_op, fct_ln_fake, _forward_only("fct_ln"))
 _define("fct_mha", "(Tensor q, Tensor k, Tensor v, Tensor in_w, Tensor? in_b, Tensor out_w, Tensor? out_b, int heads) -> Tensor", fct_mha_op,
-        fct_mha_fake)
-_define("fct_add", "(Tensor a, Tensor b) -> Tensor", fct_add_op, fct_add_fake)
-_define("fct_resample", "(Tensor x, int mode) -> Tensor", fct_resample_op, fct_resample_fake)
-_define("fct_concat", "(Tensor a, Tensor b) -> Tensor", fct_concat_op, fct_concat_fake)
-_define("dice_loss", "(Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_op, dice_loss_fake)
+        fct_mha_fake, _forward_only("fct_mha"))
+_define("fct_add", "(Tensor a, Tensor b) -> Tensor", fct_add_op, fct_add_fake, _forward_only("fct_add"))
+_define("fct_resample", "(Tensor x, int mode) -> Tensor", fct_resample_op, fct_resample_fake, _forward_only("fct_resample"))
+_define("fct_concat", "(Tensor a, Tensor b) -> Tensor", fct_concat_op, fct_concat_fake, _forward_only("fct_concat"))
+_define("dice_loss", "(Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_op, dice_loss_fake, _forward_only("dice_loss"))
