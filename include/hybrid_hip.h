@@ -318,6 +318,11 @@ size_t hyb_dice_workspace(void);
 int hyb_dice_fwd(const float* pred, const float* tru, float* loss /* [1] */, int N, int C, long long HW, float smooth, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* ---- clip input pipeline: torchvision's to-tensor transform on the device -----------------------------
+ * dst[f][c][h][w] = src[f][h][w][c] / 255 for `frames` uint8 HWC frames (what PIL / cv2 decode to; Dataloader.py:19-23,
+ * dataset.pyc src L106-113): frames cross PCIe as bytes and become the fp32 NCHW clip tensor the first conv stage reads. */
+int hyb_frames_u8hwc_to_f32chw(const unsigned char* src, float* dst, long long frames, int H, int W, int C, void* stream);
+
 /* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
  * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
  * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]

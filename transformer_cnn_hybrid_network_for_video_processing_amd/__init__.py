@@ -4,5 +4,6 @@ from .modules import (ConvBNReLUPool, HybridCrossEntropyLoss, MultiheadAttention
 from .optim import HybridAdamW  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
 from .fct import FCT, DiceLoss  # noqa: F401
+from .clips import ClipCSVDataset, ClipPipeline, SyntheticClipSource, collate_clips, t_major  # noqa: F401
 
-__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW", "GraphedTrainStep", "FCT", "DiceLoss"]
+__all__ = ["TransformerCNNHybrid", "TransformerEncoder", "MultiheadAttention", "ConvBNReLUPool", "HybridCrossEntropyLoss", "HybridAdamW", "GraphedTrainStep", "FCT", "DiceLoss", "ClipCSVDataset", "ClipPipeline", "SyntheticClipSource", "collate_clips", "t_major"]

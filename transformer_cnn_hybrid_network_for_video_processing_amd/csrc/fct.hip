@@ -391,3 +391,28 @@ extern "C" int hyb_dice_fwd(const float* pred, const float* tru, float* loss, in
     HYB_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Clip input pipeline: torchvision ToTensor on the GPU.  The reference decodes frames on the host and turns
+// each into a float CHW tensor in [0,1] (transforms.ToTensor, Dataloader.py:19-23; dataset.pyc src L106-113 for clips); moving the
+// frames over PCIe as uint8 HWC (1/4 of the bytes) and converting here gives the same values: out[f][c][h][w] = src[f][h][w][c] / 255.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void u8hwc_to_f32chw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long frames,
+                                                              int HW, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // one pixel of one frame
+    if (i >= frames * HW) return;
+    const long long f = i / HW;
+    const int pix = (int)(i - f * HW);
+    const unsigned char* s = src + i * C;
+    for (int c = 0; c < C; ++c) dst[(f * C + c) * HW + pix] = (float)s[c] / 255.0f;      // ToTensor divides by 255 (not a multiply by 1/255)
+}
+}  // namespace
+
+extern "C" int hyb_frames_u8hwc_to_f32chw(const unsigned char* src, float* dst, long long frames, int H, int W, int C, void* stream) {
+    HYB_CHECK_ARG(src && dst && frames > 0 && H > 0 && W > 0 && C > 0 && C <= 4);
+    const long long n = frames * H * W;
+    hipLaunchKernelGGL(u8hwc_to_f32chw_kernel, dim3(hyb_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, frames, H * W, C);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
