@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fwd-bwd-only", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive leg (host uint8 clips fed through clips.ClipPipeline)")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python each step instead of replaying the captured hipGraphs "
                                                          "(graph.GraphedTrainStep); same kernels and arithmetic, more host time")
     args = ap.parse_args(argv)
@@ -404,6 +405,31 @@ def main():
         fb = {"value": args.batch * world * args.steps / fdt, "unit": "clips/s", "ms_per_step": fdt / args.steps * 1e3,
               "step": "fwd+cross_entropy+bwd" + ("+grad_allreduce" if world > 1 else "") + " (no zero_grad, no optimizer); same K steps, timed after the headline"}
 
+    fed = None
+    if not args.no_pipeline and world == 1:
+        # PCIe-inclusive rate (never `value`): every step takes a NEW host batch -- uint8 frames in pinned memory, async H2D on the copy
+        # stream, ToTensor on the device, two batches ahead (clips.ClipPipeline) -- instead of HBM-resident clips
+        import itertools
+        src = P.SyntheticClipSource(args.batch, args.frames, args.size, CFG["num_classes"], seed=1000 + rank, distinct=3)
+        pipe = iter(P.ClipPipeline(itertools.islice(iter(src), args.steps + 3), device=dev, depth=2))
+
+        def fed_step():
+            xb, yb = next(pipe)
+            if graphed:
+                trainer.load(xb, yb)
+                return trainer.step()
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(xb), yb)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(3):
+            fed_step()
+        pdt, _ = timed(fed_step, args.steps)
+        fed = {"value": args.batch * args.steps / pdt, "unit": "clips/s", "ms_per_step": pdt / args.steps * 1e3,
+               "what": "same step, but each batch starts as uint8 [B,T,H,W,3] in pinned host memory and crosses PCIe (clips.ClipPipeline, "
+                       "depth 2); not the headline value"}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         labels = {2: "config 2", 4: "config 4 (long clip)", 5: "config 5 (high-res)"}
@@ -436,6 +462,8 @@ def main():
         }
         if fb is not None:
             out["fwd_bwd_only"] = fb
+        if fed is not None:
+            out["pcie_inclusive"] = fed
         if not args.no_roofline and world == 1:
             rows = instep_kernel_table(args, trainer.eager_fwd_bwd if graphed else step)
             dom = dominant_kernel(rows)
