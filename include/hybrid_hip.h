@@ -290,7 +290,8 @@ int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, cons
 /* y = act(conv3x3(x, w, stride 1, "same" zero padding, dilation) + b): nn.Conv2d(.., 3, 1, padding="same"[, dilation=d]) of
  * FCT.py:140-143, 110-113, 172-174, 194-196 followed by the ReLU / GELU / Sigmoid the reference applies next.  w [Co,Ci,3,3], b [Co] or NULL. */
 size_t hyb_fct_conv_workspace(int N, int H, int W, int Ci, int Co);
-int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Ci, int Co, int dilation,
+int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, float* z_out /* NULL, or the pre-activation [N,H,W,Co]
+                     (kept for the GELU backward) */, int N, int H, int W, int Ci, int Co, int dilation,
                      int act, void* workspace, size_t workspace_bytes, void* stream);
 /* Attention._build_projection for q, k and v in one pass (FCT.py:41-57): depthwise Conv2d(C, C, 3, padding 1, groups=C) + bias
  * -> ReLU -> LayerNorm over C.  HOST arrays of three device pointers each (q, k, v order): w [C,1,3,3], b [C] (or NULL), LayerNorm
@@ -303,9 +304,14 @@ int hyb_fct_ln_fwd(const float* x, const float* g, const float* b, float* y, lon
  * q, k, v, out [N, L, C]; in_w [3C, C], in_b [3C] (or NULL), out_w [C, C], out_b [C] (or NULL); softmax scale 1/sqrt(C/heads);
  * L = H*W tokens per image are streamed through an online softmax (nothing of size L x L is stored). */
 size_t hyb_fct_mha_workspace(int N, int L, int C, int heads);
+size_t hyb_fct_mha_saved_bytes(int N, int L, int C, int heads);
 int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, const float* in_w, const float* in_b, const float* out_w,
-                    const float* out_b, float* out, int N, int L, int C, int heads, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    const float* out_b, float* out, void* saved /* NULL, or hyb_fct_mha_saved_bytes: kept by the caller for the backward */,
+                    int N, int L, int C, int heads, void* workspace, size_t workspace_bytes, void* stream);
+size_t hyb_fct_mha_bwd_workspace(int N, int L, int C, int heads);
+int hyb_fct_mha_bwd(const float* dout, const float* q, const float* k, const float* v, const float* in_w, const float* out_w,
+                    const void* saved, float* dq, float* dk, float* dv, float* din_w, float* din_b /* or NULL */, float* dout_w,
+                    float* dout_b /* or NULL */, int N, int L, int C, int heads, void* workspace, size_t workspace_bytes, void* stream);
 /* y = a + b (torch.add, FCT.py:96,101,127-128) */
 int hyb_fct_add(const float* a, const float* b, float* y, long long n, void* stream);
 /* mode 0: nn.MaxPool2d(2) (FCT.py:147), 1: nn.AvgPool2d(2,2) (FCT.py:222), 2: nn.Upsample(scale_factor=2) nearest (FCT.py:170).
@@ -317,6 +323,28 @@ int hyb_fct_concat(const float* a, int Ca, const float* b, int Cb, float* y, lon
 size_t hyb_dice_workspace(void);
 int hyb_dice_fwd(const float* pred, const float* tru, float* loss /* [1] */, int N, int C, long long HW, float smooth, void* workspace,
                  size_t workspace_bytes, void* stream);
+
+/* ---- FCT backward (autograd of the forward entry points above; all gradients overwritten, reductions in a fixed order) -----------
+ * conv: saved = y for ReLU / sigmoid, the pre-activation z for GELU, ignored for NONE; dx may be NULL (first layer). */
+size_t hyb_fct_conv_bwd_workspace(int N, int H, int W, int Ci, int Co);
+int hyb_fct_conv_bwd(const float* dy, const float* x, const float* w, const float* saved, float* dx, float* dw, float* db /* or NULL */, int N, int H,
+                     int W, int Ci, int Co, int dilation, int act, void* workspace, size_t workspace_bytes, void* stream);
+size_t hyb_fct_qkv_proj_bwd_workspace(int N, int H, int W, int C);
+int hyb_fct_qkv_proj_bwd(const float* x, const float* const* w3, const float* const* b3, const float* const* g3, const float* const* dq3,
+                         float* dx, float* const* dw3, float* const* db3, float* const* dg3, float* const* dbeta3, int N, int H, int W,
+                         int C, float eps, void* workspace, size_t workspace_bytes, void* stream);
+size_t hyb_fct_ln_bwd_workspace(long long P, int C);
+int hyb_fct_ln_bwd(const float* dy, const float* x, const float* g, float* dx, float* dg, float* db, long long P, int C, float eps,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* mode 0: MaxPool2d(2) backward (x = the pool's input [N,H,W,C]; the gradient goes to the first maximum in scan order, like torch);
+ * mode 2: Upsample x2 backward (dy [N,2H,2W,C] -> dx [N,H,W,C]) */
+int hyb_fct_resample_bwd(int mode, const float* dy, const float* x, float* dx, int N, int H, int W, int C, void* stream);
+int hyb_fct_concat_bwd(const float* dy, float* da /* or NULL */, int Ca, float* db /* or NULL */, int Cb, long long P, void* stream);
+int hyb_dice_bwd(const float* pred, const float* tru, const float* dloss, float* dpred /* NCHW like pred */, int N, int C, long long HW, float smooth,
+                 void* workspace /* >= 4096 bytes */, size_t workspace_bytes, void* stream);
+/* nn.Dropout in train mode (FCT.py:115,146,175): y = x * keep / (1 - p), mask from the counter-based RNG keyed by (seed + *seed_inc);
+ * the backward is the same call on the gradient. */
+int hyb_fct_dropout(const float* x, float* y, long long n, float p, unsigned long long seed, const unsigned long long* seed_inc, void* stream);
 
 /* ---- clip input pipeline: torchvision's to-tensor transform on the device -----------------------------
  * dst[f][c][h][w] = src[f][h][w][c] / 255 for `frames` uint8 HWC frames (what PIL / cv2 decode to; Dataloader.py:19-23,

@@ -551,7 +551,7 @@ __device__ __forceinline__ void lds_row_frag(Frag<T>& f, const T* img, int ldi, 
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
-                                                           int L, int H, int dhp, int ld, int ldi, float scale) {
+                                                           float* __restrict__ lse, int L, int H, int dhp, int ld, int ldi, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Kimg = reinterpret_cast<T*>(smem_raw);                  // [64][ldi]
     T* Vimg = Kimg + 64 * ldi;
@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
             }
     }
     const float inv = 1.f / l;
+    if (lse && g == 0 && query < L) lse[(long long)blockIdx.y * L + query] = m + __logf(l);      // log-sum-exp of the scaled scores (backward)
 #pragma unroll
     for (int dt = 0; dt < MAXDT; ++dt)
         if (dt < DT) {
@@ -642,11 +643,202 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
         }
 }
 
+// delta[nh][q] = sum_d dO[q][d] * O[q][d]  (the softmax-backward row term; one thread per (image, head, query))
+template <typename T>
+__global__ void flash_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int N, int L, int H, int dhp, int ld) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * H * L) return;
+    const int qi = (int)(i % L);
+    const int nh = (int)(i / L), n = nh / H, h = nh - n * H;
+    const long long off = ((long long)n * L + qi) * ld + h * dhp;
+    float s = 0.f;
+    for (int d = 0; d < dhp; ++d) s += to_f32<T>(o[off + d]) * to_f32<T>(dout[off + d]);
+    delta[i] = s;
+}
+
+// dQ: workgroup = 64 queries (4 waves x 16) of one (image, head); loops over 64-key blocks staged in LDS (K and V images).
+template <typename T, int DTC>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                              const T* __restrict__ dout, const float* __restrict__ lse,
+                                                              const float* __restrict__ delta, T* __restrict__ dq, int L, int H, int dhp, int ld,
+                                                              int ldi, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Kimg = reinterpret_cast<T*>(smem_raw);
+    T* Vimg = Kimg + 64 * ldi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * dhp;
+    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    const int query = blockIdx.x * 64 + wave * 16 + p;
+    const int qrow = query < L ? query : L - 1;
+    constexpr int KSC = (DTC + 1) / 2;
+    Frag<T> fq[KSC], fg[KSC];
+#pragma unroll
+    for (int s = 0; s < KSC; ++s)
+        if (s < ks) {
+            const int f0 = s * 32 + 8 * g;
+            if (f0 < dhp) { frag_load(fq[s], q + base + (long long)qrow * ld + f0); frag_load(fg[s], dout + base + (long long)qrow * ld + f0); }
+            else { frag_zero(fq[s]); frag_zero(fg[s]); }
+        }
+    const float lse_q = lse[(long long)blockIdx.y * L + qrow], dl = delta[(long long)blockIdx.y * L + qrow];
+    f32x4 acc[DTC];
+#pragma unroll
+    for (int dt = 0; dt < DTC; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < L; kb += 64) {
+        __syncthreads();
+        for (int u = tid; u < 64 * segs; u += 256) {
+            const int r = u / segs, c = (u - r * segs) * 8;
+            Vec8<T> a, b;
+            if (kb + r < L) { a.load(k + base + (long long)(kb + r) * ld + c); b.load(v + base + (long long)(kb + r) * ld + c); }
+            else { a.zero(); b.zero(); }
+            a.store(Kimg + r * ldi + c);
+            b.store(Vimg + r * ldi + c);
+        }
+        if ((dhp & 15) != 0)
+            for (int u = tid; u < 64; u += 256) { Vec8<T> z; z.zero(); z.store(Kimg + u * ldi + dhp); }
+        __syncthreads();
+        Frag16<T> ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+                if (s < ks) {
+                    Frag<T> a, b;
+                    lds_row_frag(a, Kimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
+                    lds_row_frag(b, Vimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
+                    sT = mma32(a, fq[s], sT);
+                    dpT = mma32(b, fg[s], dpT);
+                }
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = kb + kt * 16 + 4 * g + r < L;
+                const float pv = ok ? __expf(sT[r] * scale - lse_q) : 0.f;
+                x[r] = pv * (dpT[r] - dl) * scale;
+            }
+            acc_to_frag(ds[kt], x);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DTC; ++dt)
+            if (dt < DT) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    Frag16<T> a;
+                    tr_read(a, Kimg, ldi, kt * 16, dt * 16, lane);
+                    acc[dt] = mma16(a, ds[kt], acc[dt]);
+                }
+            }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DTC; ++dt)
+        if (dt < DT) {
+            const int f0 = dt * 16 + 4 * g;
+            if (query < L && f0 < dhp) store4(dq + base + (long long)query * ld + f0, acc[dt]);
+        }
+}
+
+// dK, dV: workgroup = 64 keys (4 waves x 16) of one (image, head); loops over 64-query blocks staged in LDS (Q and dO images + lse, delta).
+template <typename T, int DTC>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                               const T* __restrict__ dout, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv, int L,
+                                                               int H, int dhp, int ld, int ldi, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Qimg = reinterpret_cast<T*>(smem_raw);
+    T* Gimg = Qimg + 64 * ldi;
+    float* lseL = reinterpret_cast<float*>(Gimg + 64 * ldi);   // [64]
+    float* delL = lseL + 64;                                   // [64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, g = lane >> 4;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * dhp;
+    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    const int key = blockIdx.x * 64 + wave * 16 + p;
+    const int krow = key < L ? key : L - 1;
+    constexpr int KSC = (DTC + 1) / 2;
+    Frag<T> fk[KSC], fv[KSC];
+#pragma unroll
+    for (int s = 0; s < KSC; ++s)
+        if (s < ks) {
+            const int f0 = s * 32 + 8 * g;
+            if (f0 < dhp) { frag_load(fk[s], k + base + (long long)krow * ld + f0); frag_load(fv[s], v + base + (long long)krow * ld + f0); }
+            else { frag_zero(fk[s]); frag_zero(fv[s]); }
+        }
+    f32x4 dkT[DTC], dvT[DTC];
+#pragma unroll
+    for (int dt = 0; dt < DTC; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qb = 0; qb < L; qb += 64) {
+        __syncthreads();
+        for (int u = tid; u < 64 * segs; u += 256) {
+            const int r = u / segs, c = (u - r * segs) * 8;
+            Vec8<T> a, b;
+            if (qb + r < L) { a.load(q + base + (long long)(qb + r) * ld + c); b.load(dout + base + (long long)(qb + r) * ld + c); }
+            else { a.zero(); b.zero(); }
+            a.store(Qimg + r * ldi + c);
+            b.store(Gimg + r * ldi + c);
+        }
+        if ((dhp & 15) != 0)
+            for (int u = tid; u < 64; u += 256) { Vec8<T> z; z.zero(); z.store(Qimg + u * ldi + dhp); z.store(Gimg + u * ldi + dhp); }
+        if (tid < 64) {
+            const bool ok = qb + tid < L;
+            lseL[tid] = ok ? lse[(long long)blockIdx.y * L + qb + tid] : 0.f;
+            delL[tid] = ok ? delta[(long long)blockIdx.y * L + qb + tid] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            f32x4 sN = f32x4{0.f, 0.f, 0.f, 0.f}, dpN = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+                if (s < ks) {
+                    Frag<T> a, b;
+                    lds_row_frag(a, Qimg, ldi, qt * 16 + p, s * 32 + 8 * g, dhp);
+                    lds_row_frag(b, Gimg, ldi, qt * 16 + p, s * 32 + 8 * g, dhp);
+                    sN = mma32(a, fk[s], sN);
+                    dpN = mma32(b, fv[s], dpN);
+                }
+            float ds[4], pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qt * 16 + 4 * g + r;
+                const bool ok = key < L && qb + ql < L;
+                pv[r] = ok ? __expf(sN[r] * scale - lseL[ql]) : 0.f;
+                ds[r] = pv[r] * (dpN[r] - delL[ql]) * scale;
+            }
+            Frag16<T> dsF, pF;
+            acc_to_frag(dsF, ds);
+            acc_to_frag(pF, pv);
+#pragma unroll
+            for (int dt = 0; dt < DTC; ++dt)
+                if (dt < DT) {
+                    Frag16<T> aq, ag;
+                    tr_read(aq, Qimg, ldi, qt * 16, dt * 16, lane);
+                    tr_read(ag, Gimg, ldi, qt * 16, dt * 16, lane);
+                    dkT[dt] = mma16(aq, dsF, dkT[dt]);
+                    dvT[dt] = mma16(ag, pF, dvT[dt]);
+                }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DTC; ++dt)
+        if (dt < DT) {
+            const int f0 = dt * 16 + 4 * g;
+            if (key < L && f0 < dhp) {
+                store4(dk + base + (long long)key * ld + f0, dkT[dt]);
+                store4(dv + base + (long long)key * ld + f0, dvT[dt]);
+            }
+        }
+}
+
 }  // namespace
 
 // Internal (fct.hip): out = softmax(q k^T * scale) v per (image, head), L tokens, heads of padded width dhp at stride ld
-int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int N, int L, int H, int dhp, int ld, float scale,
-                            hipStream_t st) {
+int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
+                            float scale, hipStream_t st) {
     if (!q || !k || !v || !out || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 || dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535) return HYB_E_ARG;
     const int es = dtype == HYB_F32 ? 4 : 2;
     int bytes = ((dhp + 15) / 16) * 16 * es;
@@ -656,10 +848,36 @@ int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void*
     const dim3 grid(hyb_cdiv(L, 64), N * H);
     if (dtype == HYB_F32) {
         if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)flash_fwd_kernel<float>, 160 * 1024)) return e; }
-        hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, L, H, dhp, ld, ldi, scale);
+        hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
     } else if (dtype == HYB_BF16) {
-        hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, L, H, dhp, ld, ldi, scale);
+        hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, L, H, dhp, ld, ldi, scale);
     } else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal (fct_bwd.hip): gradients of the long-sequence attention core.  lse from the forward pass; delta_ws: N*H*L floats of scratch.
+int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
+                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st) {
+    if (!q || !k || !v || !o || !dout || !lse || !delta_ws || !dq || !dk || !dv || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 ||
+        dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535 || dtype != HYB_F32) return HYB_E_ARG;      // fp32 only so far (FCT runs in fp32)
+    const int es = 4;
+    int bytes = ((dhp + 15) / 16) * 16 * es;
+    if ((bytes / 32) % 2 == 0) bytes += 32;
+    const int ldi = bytes / es;
+    const size_t lds = (size_t)2 * 64 * ldi * es + 2 * 64 * sizeof(float);
+    if (lds > 64 * 1024) return HYB_E_ARG;                       // 128-wide fp32 heads: 2 x 64 x 136 x 4 B = 68 KiB; FCT's widest head is 64
+    const long long nq = (long long)N * H * L;
+    hipLaunchKernelGGL(flash_delta_kernel<float>, dim3(hyb_cdiv(nq, 256)), dim3(256), 0, st, (const float*)o, (const float*)dout, delta_ws, N, L, H, dhp, ld);
+    const dim3 grid(hyb_cdiv(L, 64), N * H);
+#define FLASH_BWD(DTC_) do { \
+        hipLaunchKernelGGL((flash_bwd_dq_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \
+                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale); \
+        hipLaunchKernelGGL((flash_bwd_dkv_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \
+                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale); } while (0)
+    const int DT = (dhp + 15) / 16;
+    if (DT <= 1) FLASH_BWD(1); else if (DT <= 2) FLASH_BWD(2); else if (DT <= 4) FLASH_BWD(4); else FLASH_BWD(8);
+#undef FLASH_BWD
     HYB_LAUNCH_CHECK();
     return 0;
 }

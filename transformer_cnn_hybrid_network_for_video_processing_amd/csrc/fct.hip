@@ -16,8 +16,8 @@
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
-int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, int N, int L, int H, int dhp, int ld, float scale,
-                            hipStream_t st);
+int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
+                            float scale, hipStream_t st);
 
 namespace {
 
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 
 __device__ __forceinline__ float gelu_erf(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }      // nn.GELU() default (erf form)
 
-__global__ void act_kernel(float* __restrict__ y, long long n, int act) {
+__global__ void act_kernel(const float* __restrict__ zin, float* __restrict__ y, long long n, int act) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float z = y[i];
+    const float z = zin[i];
     y[i] = act == HYB_ACT_GELU ? gelu_erf(z) : act == HYB_ACT_SIGMOID ? 1.f / (1.f + expf(-z)) : act == HYB_ACT_RELU ? fmaxf(z, 0.f) : z;
 }
 
@@ -235,8 +235,8 @@ extern "C" size_t hyb_fct_conv_workspace(int N, int H, int W, int Ci, int Co) {
     return al256((size_t)Co * Kp * 4) + al256((size_t)nb * per_img);
 }
 
-extern "C" int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, int N, int H, int W, int Ci, int Co, int dilation,
-                                int act, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, float* z_out, int N, int H, int W, int Ci, int Co,
+                                int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(x && w && y && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && dilation >= 1 && dilation <= 8);
     HYB_CHECK_ARG(act >= HYB_ACT_NONE && act <= HYB_ACT_SIGMOID);
     if (workspace_bytes < hyb_fct_conv_workspace(N, H, W, Ci, Co)) return HYB_E_WORKSPACE;
@@ -254,12 +254,14 @@ extern "C" int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, 
         if (P > 0x7fffffff / 32 * 32) return HYB_E_ARG;
         hipLaunchKernelGGL(im2col_kernel, dim3(grid1(P * Kp)), dim3(256), 0, st, x + (long long)n0 * H * W * Ci, col, P, H, W, Ci, Kp, dilation);
         HYB_LAUNCH_CHECK();
-        const void* A[1] = {col}; const void* B[1] = {wp}; void* Cc[1] = {y + (long long)n0 * H * W * Co}; const float* bias[1] = {b};
+        // GELU / sigmoid: the GEMM leaves the pre-activation (in z_out when the caller keeps it for backward, else in y)
+        float* gemm_out = ((act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) && z_out) ? z_out : y;
+        const void* A[1] = {col}; const void* B[1] = {wp}; void* Cc[1] = {gemm_out + (long long)n0 * H * W * Co}; const float* bias[1] = {b};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, bias, 0, (int)P, Co, Kp, Kp, Kp, Co, act == HYB_ACT_RELU, 0, st));
     }
     if (act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) {
         const long long n = (long long)N * H * W * Co;
-        hipLaunchKernelGGL(act_kernel, dim3(grid1(n)), dim3(256), 0, st, y, n, act);
+        hipLaunchKernelGGL(act_kernel, dim3(grid1(n)), dim3(256), 0, st, z_out ? (const float*)z_out : (const float*)y, y, n, act);
         HYB_LAUNCH_CHECK();
     }
     return 0;
@@ -324,9 +326,15 @@ extern "C" size_t hyb_fct_mha_workspace(int N, int L, int C, int heads) {
     return al256((size_t)3 * Cp * C * 4) + al256((size_t)3 * Cp * 4) + al256((size_t)C * Cp * 4) + 4 * al256(M * Cp * 4);
 }
 
+extern "C" size_t hyb_fct_mha_saved_bytes(int N, int L, int C, int heads) {
+    if (N < 1 || L < 1 || C < 1 || heads < 1 || C % heads != 0) return 0;
+    const int Cp = heads * up8(C / heads);
+    return 4 * al256((size_t)N * L * Cp * 4) + al256((size_t)N * heads * L * 4);
+}
+
 extern "C" int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, const float* in_w, const float* in_b, const float* out_w,
-                               const float* out_b, float* out, int N, int L, int C, int heads, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               const float* out_b, float* out, void* saved, int N, int L, int C, int heads, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(q && k && v && in_w && out_w && out && workspace && N > 0 && L > 0 && C > 0 && heads > 0 && C % heads == 0 && C % 8 == 0);
     if (workspace_bytes < hyb_fct_mha_workspace(N, L, C, heads)) return HYB_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -338,7 +346,9 @@ extern "C" int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, c
     float* bin = (float*)ws;   ws += al256((size_t)3 * Cp * 4);
     float* wout = (float*)ws;  ws += al256((size_t)C * Cp * 4);
     const size_t act = al256((size_t)M * Cp * 4);
+    if (saved) ws = (char*)saved;                              // kept for backward: projected q, k, v, the attention output and the row log-sum-exps
     float* Q = (float*)ws; float* K = (float*)(ws + act); float* V = (float*)(ws + 2 * act); float* A = (float*)(ws + 3 * act);
+    float* lse = saved ? (float*)(ws + 4 * act) : nullptr;
     const int total = 3 * Cp * C + 3 * Cp + C * Cp;
     hipLaunchKernelGGL(mha_pack_kernel, dim3(grid1(total)), dim3(256), 0, st, in_w, in_b, out_w, win, bin, wout, C, heads, dh, dhp);
     HYB_LAUNCH_CHECK();
@@ -347,7 +357,7 @@ extern "C" int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, c
         void* Cs[3] = {Q, K, V}; const float* bs[3] = {bin, bin + Cp, bin + 2 * Cp};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 3, As, Bs, Cs, bs, 0, (int)M, Cp, C, C, C, Cp, 0, 0, st));
     }
-    FCT_TRY(hyb_flash_attention_fwd(HYB_F32, Q, K, V, A, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st));
+    FCT_TRY(hyb_flash_attention_fwd(HYB_F32, Q, K, V, A, lse, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st));
     {   // out-projection
         const void* As[1] = {A}; const void* Bs[1] = {wout}; void* Cs[1] = {out}; const float* bs[1] = {out_b};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, As, Bs, Cs, bs, 0, (int)M, C, Cp, Cp, Cp, C, 0, 0, st));

@@ -7,8 +7,8 @@ names are the reference's (``block_1.conv1_a.weight`` .. ``ds.conv3.bias``; the 
 names and are never called themselves), so checkpoints written by the reference harness (FCT.py:366-373) load unchanged.
 Clips are fed frame-folded, ``[B*T,3,H,W]`` (north_star: "folded over B*T").
 
-STATUS: forward (inference, ``.eval()``) on the GPU; the train-mode forward (dropout 0.3 / 0.1, FCT.py:115,146,175) and the
-backward are the next step of this row and raise until then.  There is no CPU fallback.
+Forward and backward run on the GPU in exact fp32 (fp32-input MFMA); train mode applies the reference's dropouts (0.3 after the
+conv pairs, FCT.py:146,175; 0.1 inside Wide_Focus, FCT.py:115) with the library's counter-based masks.  There is no CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -17,7 +17,12 @@ from . import ops
 
 
 def _conv(c, x, act, dilation=1):
-    return torch.ops.hybrid.fct_conv(x, c.weight, c.bias, dilation, act)
+    return torch.ops.hybrid.fct_conv(x, c.weight, c.bias, dilation, act)[0]
+
+
+def _drop(x, p, training):
+    """nn.Dropout(p) (FCT.py:115,146,175): identity in eval mode."""
+    return torch.ops.hybrid.fct_dropout(x, p, ops.next_seed(), ops.step_counter()) if training and p > 0.0 else x
 
 
 class Attention(nn.Module):                                       # parameter names of FCT.py:24-39
@@ -39,7 +44,7 @@ class Attention(nn.Module):                                       # parameter na
                                                 [l.bias for l in lns], lns[0].eps)
         a = self.attention
         out = torch.ops.hybrid.fct_mha(q.view(N, H * W, C), k.view(N, H * W, C), v.view(N, H * W, C), a.in_proj_weight, a.in_proj_bias,
-                                       a.out_proj.weight, a.out_proj.bias, self.num_heads)
+                                       a.out_proj.weight, a.out_proj.bias, self.num_heads)[0]
         return out.view(N, H, W, C)
 
 
@@ -51,10 +56,11 @@ class Wide_Focus(nn.Module):                                      # FCT.py:107-1
         self.conv3 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same", dilation=3)
         self.conv4 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
 
-    def forward(self, x):                                         # FCT.py:117-132 (eval: dropout is the identity)
-        added = torch.ops.hybrid.fct_add(torch.ops.hybrid.fct_add(_conv(self.conv1, x, ops.ACT_GELU, 1), _conv(self.conv2, x, ops.ACT_GELU, 2)),
-                                         _conv(self.conv3, x, ops.ACT_GELU, 3))
-        return _conv(self.conv4, added, ops.ACT_GELU, 1)
+    def forward(self, x):                                         # FCT.py:117-132
+        t = self.training
+        x1, x2, x3 = (_drop(_conv(c, x, ops.ACT_GELU, d), 0.1, t) for c, d in ((self.conv1, 1), (self.conv2, 2), (self.conv3, 3)))
+        added = torch.ops.hybrid.fct_add(torch.ops.hybrid.fct_add(x1, x2), x3)
+        return _drop(_conv(self.conv4, added, ops.ACT_GELU, 1), 0.1, t)
 
 
 class Transformer(nn.Module):                                     # FCT.py:84-91
@@ -87,7 +93,7 @@ class Block_encoder_bottleneck(nn.Module):                        # FCT.py:136-1
         else:
             x1 = torch.ops.hybrid.fct_concat(_conv(self.conv1_b, scale_img, ops.ACT_RELU), x)
             x1 = _conv(self.conv3, _conv(self.conv2, x1, ops.ACT_RELU), ops.ACT_RELU)
-        return self.trans(torch.ops.hybrid.fct_resample(x1, 0))
+        return self.trans(torch.ops.hybrid.fct_resample(_drop(x1, 0.3, self.training), 0))
 
 
 class Block_decoder(nn.Module):                                   # FCT.py:167-175
@@ -101,7 +107,7 @@ class Block_decoder(nn.Module):                                   # FCT.py:167-1
     def forward(self, x, skip):                                   # FCT.py:177-186
         x1 = _conv(self.conv1, torch.ops.hybrid.fct_resample(x, 2), ops.ACT_RELU)
         x1 = torch.ops.hybrid.fct_concat(skip, x1)
-        return self.trans(_conv(self.conv3, _conv(self.conv2, x1, ops.ACT_RELU), ops.ACT_RELU))
+        return self.trans(_drop(_conv(self.conv3, _conv(self.conv2, x1, ops.ACT_RELU), ops.ACT_RELU), 0.3, self.training))
 
 
 class DS_out(nn.Module):                                          # FCT.py:191-198
@@ -141,9 +147,6 @@ class FCT(nn.Module):
         if x.shape[2] % 32 != 0 or x.shape[3] != x.shape[2]:
             # the reference fails at its skip concat (FCT.py:181) / its square-map view (FCT.py:77) for any other size
             raise RuntimeError(f"FCT needs square inputs with H = W a multiple of 32 (got {tuple(x.shape[2:])})")
-        if self.training:
-            raise NotImplementedError("FCT on the HIP path is forward-only so far: call .eval() (train-mode dropout and the backward are "
-                                      "the next step of SURVEY.md section 8f-1)")
         B, _, H, W = x.shape
         x = ops.nchw_to_nhwc(x, ops.HYB_F32, 3)                                   # NHWC fp32, 3 channels
         s2 = torch.ops.hybrid.fct_resample(x, 1)                                  # multi-scale input pyramid, FCT.py:238-240
@@ -158,7 +161,7 @@ class FCT(nn.Module):
         y = self.block_7(y, x3)
         y = self.block_8(y, x2)
         y = self.block_9(y, x1)
-        return ops.nhwc_to_nchw(self.ds(y), ops.HYB_F32, 1)                       # [B,1,H,W]
+        return self.ds(y).reshape(B, 1, H, W)                                     # one channel: NHWC and NCHW coincide
 
 
 class DiceLoss(nn.Module):

@@ -1067,8 +1067,9 @@ _define("temporal_bwd", "(Tensor dlogits, Tensor token_w, Tensor[] enc_params, T
 
 
 # ---------------------------------------------------------------------------------------------
-# FCT forward operators (FCT.py:24-254).  NHWC fp32 tensors with the true channel count.  Forward only:
-# no Autograd kernel is registered, so a backward through them fails loudly ("no autograd formula was registered").
+# FCT operators (FCT.py:24-254, Metrics.py:5-22), forward and backward.  NHWC fp32 tensors with the true
+# channel count.  Same registration scheme as above: backend + fake kernels for every operator, an autograd Function on the
+# Autograd key of the differentiable ones, each backward a hybrid::*_bwd operator.
 # ---------------------------------------------------------------------------------------------
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -1077,21 +1078,67 @@ def _f32c(t):
     return t.contiguous().float()
 
 
-def fct_conv_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dilation: int, act: int) -> Tensor:
+def _e0(ref):
+    return torch.empty(0, dtype=torch.float32, device=ref.device)
+
+
+def fct_conv_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], dilation: int, act: int) -> Tuple[Tensor, Tensor]:
+    """-> (y, z): z is the pre-activation, kept only for GELU (its backward needs it), else empty."""
     _require_cuda(x, weight)
     x = _f32c(x)
     N, H, W, Ci = x.shape
     Co = weight.shape[0]
     y = torch.empty(N, H, W, Co, dtype=torch.float32, device=x.device)
+    z = torch.empty_like(y) if act == ACT_GELU else _e0(x)
     ws = _ws(_query("hyb_fct_conv_workspace", N, H, W, Ci, Co), x.device)
     lib.call("hyb_fct_conv_fwd", x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr() if bias is not None else None, y.data_ptr(),
-             N, H, W, Ci, Co, dilation, act, ws.data_ptr(), ws.numel(), _stream())
-    return y
+             z.data_ptr() if act == ACT_GELU else None, N, H, W, Ci, Co, dilation, act, ws.data_ptr(), ws.numel(), _stream())
+    return y, z
 
 
 def fct_conv_fake(x, weight, bias, dilation, act):
     N, H, W, _ = x.shape
-    return x.new_empty((N, H, W, weight.shape[0]), dtype=torch.float32)
+    y = x.new_empty((N, H, W, weight.shape[0]), dtype=torch.float32)
+    return y, (torch.empty_like(y) if act == ACT_GELU else x.new_empty((0,), dtype=torch.float32))
+
+
+def fct_conv_bwd_op(dy: Tensor, x: Tensor, weight: Tensor, saved: Tensor, has_bias: bool, need_dx: bool, dilation: int,
+                    act: int) -> Tuple[Tensor, Tensor, Tensor]:
+    _require_cuda(dy, x)
+    dy, x = _f32c(dy), _f32c(x)
+    N, H, W, Ci = x.shape
+    Co = weight.shape[0]
+    dx = torch.empty_like(x) if need_dx else _e0(x)
+    dw = torch.empty_like(weight, memory_format=torch.contiguous_format, dtype=torch.float32)
+    db = torch.empty(Co if has_bias else 0, dtype=torch.float32, device=x.device)
+    ws = _ws(_query("hyb_fct_conv_bwd_workspace", N, H, W, Ci, Co), x.device)
+    lib.call("hyb_fct_conv_bwd", dy.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), saved.data_ptr() if act != ACT_NONE else None,
+             dx.data_ptr() if need_dx else None, dw.data_ptr(), db.data_ptr() if has_bias else None, N, H, W, Ci, Co, dilation, act,
+             ws.data_ptr(), ws.numel(), _stream())
+    return dx, dw, db
+
+
+def fct_conv_bwd_fake(dy, x, weight, saved, has_bias, need_dx, dilation, act):
+    return ((torch.empty_like(x) if need_dx else x.new_empty((0,))), torch.empty_like(weight, memory_format=torch.contiguous_format),
+            x.new_empty((weight.shape[0] if has_bias else 0,)))
+
+
+class _FctConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation, act):
+        with _below_autograd():
+            y, z = torch.ops.hybrid.fct_conv(x, weight, bias, dilation, act)
+        ctx.save_for_backward(x, weight, z if act == ACT_GELU else y)
+        ctx.cfg = (bias is not None, dilation, act)
+        ctx.mark_non_differentiable(z)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, dy, unused):
+        x, weight, saved = ctx.saved_tensors
+        has_bias, dilation, act = ctx.cfg
+        dx, dw, db = torch.ops.hybrid.fct_conv_bwd(dy, x, weight, saved, has_bias, ctx.needs_input_grad[0], dilation, act)
+        return (dx if ctx.needs_input_grad[0] else None), dw, (db if has_bias else None), None, None
 
 
 def fct_qkv_proj_op(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor], ln_weights: Sequence[Tensor], ln_biases: Sequence[Tensor],
@@ -1112,6 +1159,47 @@ def fct_qkv_proj_fake(x, weights, biases, ln_weights, ln_biases, eps):
     return e(), e(), e()
 
 
+def fct_qkv_proj_bwd_op(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor], ln_weights: Sequence[Tensor], dqs: Sequence[Tensor],
+                        eps: float) -> List[Tensor]:
+    """-> [dx, dw_q, dw_k, dw_v, db_q, db_k, db_v, dg_q, dg_k, dg_v, dbeta_q, dbeta_k, dbeta_v]"""
+    _require_cuda(x, *dqs)
+    x = _f32c(x)
+    N, H, W, C = x.shape
+    dev = x.device
+    ws_, bs_, gs_, dq_ = ([_f32c(t) for t in lst] for lst in (weights, biases, ln_weights, dqs))
+    dx = torch.empty_like(x)
+    dws = [torch.empty(C, 1, 3, 3, dtype=torch.float32, device=dev) for _ in range(3)]
+    dbs, dgs, dbetas = ([torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3)] for _ in range(3))
+    ws = _ws(_query("hyb_fct_qkv_proj_bwd_workspace", N, H, W, C), dev)
+    pa = lambda lst: ptr_array([t.data_ptr() for t in lst])
+    lib.call("hyb_fct_qkv_proj_bwd", x.data_ptr(), pa(ws_), pa(bs_), pa(gs_), pa(dq_), dx.data_ptr(), pa(dws), pa(dbs), pa(dgs), pa(dbetas),
+             N, H, W, C, float(eps), ws.data_ptr(), ws.numel(), _stream())
+    return [dx] + dws + dbs + dgs + dbetas
+
+
+def fct_qkv_proj_bwd_fake(x, weights, biases, ln_weights, dqs, eps):
+    C = x.shape[-1]
+    v = lambda: x.new_empty((C,), dtype=torch.float32)
+    return [torch.empty_like(x)] + [x.new_empty((C, 1, 3, 3), dtype=torch.float32) for _ in range(3)] + [v() for _ in range(9)]
+
+
+class _FctQkvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, *t):                               # t = 3 weights, 3 biases, 3 LN weights, 3 LN biases
+        with _below_autograd():
+            out = torch.ops.hybrid.fct_qkv_proj(x, t[0:3], t[3:6], t[6:9], t[9:12], eps)
+        ctx.save_for_backward(x, *t[0:9])
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x, *t = ctx.saved_tensors
+        z = lambda g: g if g is not None else torch.zeros_like(x)
+        r = torch.ops.hybrid.fct_qkv_proj_bwd(x, t[0:3], t[3:6], t[6:9], [z(dq), z(dk), z(dv)], ctx.eps)
+        return (r[0], None) + tuple(r[1:])
+
+
 def fct_ln_op(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
     _require_cuda(x, weight)
     x = _f32c(x)
@@ -1125,21 +1213,100 @@ def fct_ln_fake(x, weight, bias, eps):
     return x.new_empty(x.shape, dtype=torch.float32)
 
 
-def fct_mha_op(q: Tensor, k: Tensor, v: Tensor, in_w: Tensor, in_b: Optional[Tensor], out_w: Tensor, out_b: Optional[Tensor], heads: int) -> Tensor:
-    """q, k, v [N, L, C] (pixel tokens) -> nn.MultiheadAttention output [N, L, C]."""
+def fct_ln_bwd_op(dy: Tensor, x: Tensor, weight: Tensor, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    _require_cuda(dy, x)
+    dy, x = _f32c(dy), _f32c(x)
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dg, db = (torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(2))
+    ws = _ws(_query("hyb_fct_ln_bwd_workspace", P, C), x.device)
+    lib.call("hyb_fct_ln_bwd", dy.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), P, C, float(eps),
+             ws.data_ptr(), ws.numel(), _stream())
+    return dx, dg, db
+
+
+def fct_ln_bwd_fake(dy, x, weight, eps):
+    C = x.shape[-1]
+    return torch.empty_like(x), x.new_empty((C,), dtype=torch.float32), x.new_empty((C,), dtype=torch.float32)
+
+
+class _FctLnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        with _below_autograd():
+            return torch.ops.hybrid.fct_ln(x, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dg, db = torch.ops.hybrid.fct_ln_bwd(dy, x, weight, ctx.eps)
+        return dx, dg, db, None
+
+
+def fct_mha_op(q: Tensor, k: Tensor, v: Tensor, in_w: Tensor, in_b: Optional[Tensor], out_w: Tensor, out_b: Optional[Tensor],
+               heads: int) -> Tuple[Tensor, Tensor]:
+    """q, k, v [N, L, C] (pixel tokens) -> (nn.MultiheadAttention output [N, L, C], blob saved for backward)."""
     _require_cuda(q, in_w)
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     N, L, C = q.shape
     out = torch.empty_like(q)
+    saved = _ws(_query("hyb_fct_mha_saved_bytes", N, L, C, heads), q.device)
     ws = _ws(_query("hyb_fct_mha_workspace", N, L, C, heads), q.device)
     lib.call("hyb_fct_mha_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _f32c(in_w).data_ptr(), _f32c(in_b).data_ptr() if in_b is not None else None,
-             _f32c(out_w).data_ptr(), _f32c(out_b).data_ptr() if out_b is not None else None, out.data_ptr(), N, L, C, heads, ws.data_ptr(), ws.numel(),
-             _stream())
-    return out
+             _f32c(out_w).data_ptr(), _f32c(out_b).data_ptr() if out_b is not None else None, out.data_ptr(), saved.data_ptr(), N, L, C, heads,
+             ws.data_ptr(), ws.numel(), _stream())
+    return out, saved
 
 
 def fct_mha_fake(q, k, v, in_w, in_b, out_w, out_b, heads):
-    return q.new_empty(q.shape, dtype=torch.float32)
+    N, L, C = q.shape
+    return q.new_empty(q.shape, dtype=torch.float32), q.new_empty((max(_query("hyb_fct_mha_saved_bytes", N, L, C, heads), 256),), dtype=torch.uint8)
+
+
+def fct_mha_bwd_op(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, in_w: Tensor, out_w: Tensor, saved: Tensor, heads: int, has_in_b: bool,
+                   has_out_b: bool) -> List[Tensor]:
+    """-> [dq, dk, dv, din_w, din_b, dout_w, dout_b]"""
+    _require_cuda(dout, q)
+    dout, q, k, v = _f32c(dout), _f32c(q), _f32c(k), _f32c(v)
+    N, L, C = q.shape
+    dev = q.device
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    din_w = torch.empty(3 * C, C, dtype=torch.float32, device=dev)
+    din_b = torch.empty(3 * C if has_in_b else 0, dtype=torch.float32, device=dev)
+    dout_w = torch.empty(C, C, dtype=torch.float32, device=dev)
+    dout_b = torch.empty(C if has_out_b else 0, dtype=torch.float32, device=dev)
+    ws = _ws(_query("hyb_fct_mha_bwd_workspace", N, L, C, heads), dev)
+    lib.call("hyb_fct_mha_bwd", dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), _f32c(in_w).data_ptr(), _f32c(out_w).data_ptr(),
+             saved.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), din_w.data_ptr(), din_b.data_ptr() if has_in_b else None,
+             dout_w.data_ptr(), dout_b.data_ptr() if has_out_b else None, N, L, C, heads, ws.data_ptr(), ws.numel(), _stream())
+    return [dq, dk, dv, din_w, din_b, dout_w, dout_b]
+
+
+def fct_mha_bwd_fake(dout, q, k, v, in_w, out_w, saved, heads, has_in_b, has_out_b):
+    C = q.shape[-1]
+    f = lambda *s: q.new_empty(s, dtype=torch.float32)
+    return [torch.empty_like(q), torch.empty_like(q), torch.empty_like(q), f(3 * C, C), f(3 * C if has_in_b else 0), f(C, C), f(C if has_out_b else 0)]
+
+
+class _FctMhaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, in_w, in_b, out_w, out_b, heads):
+        with _below_autograd():
+            out, saved = torch.ops.hybrid.fct_mha(q, k, v, in_w, in_b, out_w, out_b, heads)
+        ctx.save_for_backward(q, k, v, in_w, out_w, saved)
+        ctx.cfg = (heads, in_b is not None, out_b is not None)
+        ctx.mark_non_differentiable(saved)
+        return out, saved
+
+    @staticmethod
+    def backward(ctx, dout, unused):
+        q, k, v, in_w, out_w, saved = ctx.saved_tensors
+        heads, hib, hob = ctx.cfg
+        r = torch.ops.hybrid.fct_mha_bwd(dout, q, k, v, in_w, out_w, saved, heads, hib, hob)
+        return r[0], r[1], r[2], r[3], (r[4] if hib else None), r[5], (r[6] if hob else None), None
 
 
 def fct_add_op(a: Tensor, b: Tensor) -> Tensor:
@@ -1154,6 +1321,17 @@ def fct_add_op(a: Tensor, b: Tensor) -> Tensor:
 
 def fct_add_fake(a, b):
     return a.new_empty(a.shape, dtype=torch.float32)
+
+
+class _FctAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        with _below_autograd():
+            return torch.ops.hybrid.fct_add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
 
 
 def fct_resample_op(x: Tensor, mode: int) -> Tensor:
@@ -1171,6 +1349,35 @@ def fct_resample_fake(x, mode):
     return x.new_empty((N, 2 * H, 2 * W, C) if mode == 2 else (N, H // 2, W // 2, C), dtype=torch.float32)
 
 
+def fct_resample_bwd_op(dy: Tensor, x: Tensor, mode: int) -> Tensor:
+    _require_cuda(dy, x)
+    dy, x = _f32c(dy), _f32c(x)
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib.call("hyb_fct_resample_bwd", mode, dy.data_ptr(), x.data_ptr(), dx.data_ptr(), N, H, W, C, _stream())
+    return dx
+
+
+def fct_resample_bwd_fake(dy, x, mode):
+    return torch.empty_like(x)
+
+
+class _FctResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        if mode == 1 and ctx.needs_input_grad[0]:
+            raise NotImplementedError("AvgPool2d is applied to the input frames only (FCT.py:238-240): no backward")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        with _below_autograd():
+            return torch.ops.hybrid.fct_resample(x, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return torch.ops.hybrid.fct_resample_bwd(dy, x, ctx.mode), None
+
+
 def fct_concat_op(a: Tensor, b: Tensor) -> Tensor:
     _require_cuda(a, b)
     a, b = _f32c(a), _f32c(b)
@@ -1183,6 +1390,56 @@ def fct_concat_op(a: Tensor, b: Tensor) -> Tensor:
 
 def fct_concat_fake(a, b):
     return a.new_empty((*a.shape[:-1], a.shape[-1] + b.shape[-1]), dtype=torch.float32)
+
+
+def fct_concat_bwd_op(dy: Tensor, Ca: int, Cb: int) -> Tuple[Tensor, Tensor]:
+    _require_cuda(dy)
+    dy = _f32c(dy)
+    da = torch.empty(*dy.shape[:-1], Ca, dtype=torch.float32, device=dy.device)
+    db = torch.empty(*dy.shape[:-1], Cb, dtype=torch.float32, device=dy.device)
+    lib.call("hyb_fct_concat_bwd", dy.data_ptr(), da.data_ptr(), Ca, db.data_ptr(), Cb, dy.numel() // (Ca + Cb), _stream())
+    return da, db
+
+
+def fct_concat_bwd_fake(dy, Ca, Cb):
+    return dy.new_empty((*dy.shape[:-1], Ca)), dy.new_empty((*dy.shape[:-1], Cb))
+
+
+class _FctConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.cfg = (a.shape[-1], b.shape[-1])
+        with _below_autograd():
+            return torch.ops.hybrid.fct_concat(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return torch.ops.hybrid.fct_concat_bwd(dy, *ctx.cfg)
+
+
+def fct_dropout_op(x: Tensor, p: float, seed: int, seed_inc: Optional[Tensor] = None) -> Tensor:
+    _require_cuda(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    lib.call("hyb_fct_dropout", x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, _opt_ptr(seed_inc), _stream())
+    return y
+
+
+def fct_dropout_fake(x, p, seed, seed_inc=None):
+    return x.new_empty(x.shape, dtype=torch.float32)
+
+
+class _FctDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, seed_inc):
+        ctx.cfg = (p, seed)
+        ctx.seed_inc = seed_inc
+        with _below_autograd():
+            return torch.ops.hybrid.fct_dropout(x, p, seed, seed_inc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return torch.ops.hybrid.fct_dropout(dy, *ctx.cfg, ctx.seed_inc), None, None, None
 
 
 def dice_loss_op(pred: Tensor, true: Tensor, smooth: float) -> Tensor:
@@ -1203,46 +1460,54 @@ def dice_loss_fake(pred, true, smooth):
     return pred.new_empty((), dtype=torch.float32)
 
 
-class _ForwardOnlyFn(torch.autograd.Function):
-    """Autograd-key kernel of the forward-only FCT operators: the forward runs; a backward through it raises instead of passing
-    silently (torch's default for an operator without an autograd formula is a warning)."""
+def dice_loss_bwd_op(dloss: Tensor, pred: Tensor, true: Tensor, smooth: float) -> Tensor:
+    _require_cuda(dloss, pred)
+    pred, true = _f32c(pred), _f32c(true)
+    N, C = pred.shape[0], pred.shape[1]
+    dpred = torch.empty_like(pred)
+    ws = _ws(4096, pred.device)
+    lib.call("hyb_dice_bwd", pred.data_ptr(), true.data_ptr(), _f32c(dloss).reshape(1).data_ptr(), dpred.data_ptr(), N, C, pred.numel() // (N * C),
+             float(smooth), ws.data_ptr(), ws.numel(), _stream())
+    return dpred
 
+
+def dice_loss_bwd_fake(dloss, pred, true, smooth):
+    return torch.empty_like(pred)
+
+
+class _DiceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, name, nlists, *flat):
-        args, i = [], 0
-        for n in nlists:                                       # re-nest the tensor-list arguments (n < 0: a single argument)
-            if n < 0:
-                args.append(flat[i]); i += 1
-            else:
-                args.append(list(flat[i:i + n])); i += n
-        ctx.name = name
+    def forward(ctx, pred, true, smooth):
+        ctx.save_for_backward(pred, true)
+        ctx.smooth = smooth
         with _below_autograd():
-            return getattr(torch.ops.hybrid, name)(*args)
+            return torch.ops.hybrid.dice_loss(pred, true, smooth)
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(f"hybrid::{ctx.name} is forward-only so far: the FCT backward is the next step of SURVEY.md section 8f-1")
+    def backward(ctx, dloss):
+        pred, true = ctx.saved_tensors
+        return torch.ops.hybrid.dice_loss_bwd(dloss, pred, true, ctx.smooth), None, None
 
 
-def _forward_only(name):
-    def kernel(*args):
-        nlists, flat = [], []
-        for a in args:
-            if isinstance(a, (list, tuple)):
-                nlists.append(len(a)); flat += list(a)
-            else:
-                nlists.append(-1); flat.append(a)
-        return _ForwardOnlyFn.apply(name, tuple(nlists), *flat)
-    return kernel
-
-
-_define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> Tensor", fct_conv_op, fct_conv_fake, _forward_only("fct_conv"))
+_define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> (Tensor, Tensor)", fct_conv_op, fct_conv_fake, _FctConvFn.apply)
+_define("fct_conv_bwd", "(Tensor dy, Tensor x, Tensor weight, Tensor saved, bool has_bias, bool need_dx, int dilation, int act) -> (Tensor, Tensor, Tensor)",
+        fct_conv_bwd_op, fct_conv_bwd_fake)
 _define("fct_qkv_proj", "(Tensor x, Tensor[] weights, Tensor[] biases, Tensor[] ln_weights, Tensor[] ln_biases, float eps) -> (Tensor, Tensor, Tensor)",
-        fct_qkv_proj_op, fct_qkv_proj_fake, _forward_only("fct_qkv_proj"))
-_define("fct_ln", "(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", fct_ln_op, fct_ln_fake, _forward_only("fct_ln"))
-_define("fct_mha", "(Tensor q, Tensor k, Tensor v, Tensor in_w, Tensor? in_b, Tensor out_w, Tensor? out_b, int heads) -> Tensor", fct_mha_op,
-        fct_mha_fake, _forward_only("fct_mha"))
-_define("fct_add", "(Tensor a, Tensor b) -> Tensor", fct_add_op, fct_add_fake, _forward_only("fct_add"))
-_define("fct_resample", "(Tensor x, int mode) -> Tensor", fct_resample_op, fct_resample_fake, _forward_only("fct_resample"))
-_define("fct_concat", "(Tensor a, Tensor b) -> Tensor", fct_concat_op, fct_concat_fake, _forward_only("fct_concat"))
-_define("dice_loss", "(Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_op, dice_loss_fake, _forward_only("dice_loss"))
+        fct_qkv_proj_op, fct_qkv_proj_fake, lambda x, ws, bs, gs, be, eps: _FctQkvFn.apply(x, eps, *ws, *bs, *gs, *be))
+_define("fct_qkv_proj_bwd", "(Tensor x, Tensor[] weights, Tensor[] biases, Tensor[] ln_weights, Tensor[] dqs, float eps) -> Tensor[]",
+        fct_qkv_proj_bwd_op, fct_qkv_proj_bwd_fake)
+_define("fct_ln", "(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", fct_ln_op, fct_ln_fake, _FctLnFn.apply)
+_define("fct_ln_bwd", "(Tensor dy, Tensor x, Tensor weight, float eps) -> (Tensor, Tensor, Tensor)", fct_ln_bwd_op, fct_ln_bwd_fake)
+_define("fct_mha", "(Tensor q, Tensor k, Tensor v, Tensor in_w, Tensor? in_b, Tensor out_w, Tensor? out_b, int heads) -> (Tensor, Tensor)", fct_mha_op,
+        fct_mha_fake, _FctMhaFn.apply)
+_define("fct_mha_bwd", "(Tensor dout, Tensor q, Tensor k, Tensor v, Tensor in_w, Tensor out_w, Tensor saved, int heads, bool has_in_b, bool has_out_b) "
+        "-> Tensor[]", fct_mha_bwd_op, fct_mha_bwd_fake)
+_define("fct_add", "(Tensor a, Tensor b) -> Tensor", fct_add_op, fct_add_fake, _FctAddFn.apply)
+_define("fct_resample", "(Tensor x, int mode) -> Tensor", fct_resample_op, fct_resample_fake, _FctResampleFn.apply)
+_define("fct_resample_bwd", "(Tensor dy, Tensor x, int mode) -> Tensor", fct_resample_bwd_op, fct_resample_bwd_fake)
+_define("fct_concat", "(Tensor a, Tensor b) -> Tensor", fct_concat_op, fct_concat_fake, _FctConcatFn.apply)
+_define("fct_concat_bwd", "(Tensor dy, int Ca, int Cb) -> (Tensor, Tensor)", fct_concat_bwd_op, fct_concat_bwd_fake)
+_define("fct_dropout", "(Tensor x, float p, int seed, Tensor? seed_inc=None) -> Tensor", fct_dropout_op, fct_dropout_fake,
+        lambda x, p, seed, seed_inc=None: _FctDropoutFn.apply(x, p, seed, seed_inc))
+_define("dice_loss", "(Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_op, dice_loss_fake, _DiceFn.apply)
+_define("dice_loss_bwd", "(Tensor dloss, Tensor pred, Tensor true, float smooth) -> Tensor", dice_loss_bwd_op, dice_loss_bwd_fake)
