@@ -274,3 +274,47 @@ def test_dropout_seeds_differ_per_rank(monkeypatch):
     o._SEED_COUNTER[0] = 0
     b = o.next_seed()
     assert a != b and 0 <= a < 2 ** 63 and 0 <= b < 2 ** 63
+
+
+def test_opcheck_fct_operators():
+    """The FCT operators: schema, fake kernels, autograd registration and AOT dispatch."""
+    ops()
+    torch.manual_seed(9)
+    dev = "cuda"
+    x = torch.randn(2, 8, 8, 8, device=dev, requires_grad=True)
+    w = (torch.randn(16, 8, 3, 3, device=dev) * 0.1).requires_grad_(True)
+    b = torch.randn(16, device=dev).requires_grad_(True)
+    for act, dil in ((0, 1), (1, 1), (2, 2), (3, 3)):
+        _opcheck(torch.ops.hybrid.fct_conv.default, (x, w, b, dil, act))
+        y, z = torch.ops.hybrid.fct_conv(x.detach(), w.detach(), b.detach(), dil, act)
+        _opcheck(torch.ops.hybrid.fct_conv_bwd.default, (torch.randn_like(y), x.detach(), w.detach(), z if act == 2 else y, True, True, dil, act))
+    _opcheck(torch.ops.hybrid.fct_conv.default, (x, w, None, 1, 1))
+    C = 8
+    mk = lambda *s: (torch.randn(*s, device=dev) * 0.3).requires_grad_(True)
+    ws_, bs_, gs_, be_ = [mk(C, 1, 3, 3) for _ in range(3)], [mk(C) for _ in range(3)], [mk(C) for _ in range(3)], [mk(C) for _ in range(3)]
+    _opcheck(torch.ops.hybrid.fct_qkv_proj.default, (x, ws_, bs_, gs_, be_, 1e-5))
+    det = lambda lst: [t.detach() for t in lst]
+    _opcheck(torch.ops.hybrid.fct_qkv_proj_bwd.default, (x.detach(), det(ws_), det(bs_), det(gs_), [torch.randn(2, 8, 8, 8, device=dev) for _ in range(3)], 1e-5))
+    _opcheck(torch.ops.hybrid.fct_ln.default, (x, gs_[0], be_[0], 1e-5))
+    _opcheck(torch.ops.hybrid.fct_ln_bwd.default, (torch.randn_like(x), x.detach(), gs_[0].detach(), 1e-5))
+    # [N, L, C] = [2, 32, 16], 2 heads: every field of the saved blob ends on a 256-byte boundary (no uninitialised gap bytes)
+    q, k, v = (torch.randn(2, 32, 16, device=dev, requires_grad=True) for _ in range(3))
+    in_w, in_b, out_w, out_b = mk(48, 16), mk(48), mk(16, 16), mk(16)
+    _opcheck(torch.ops.hybrid.fct_mha.default, (q, k, v, in_w, in_b, out_w, out_b, 2))
+    _opcheck(torch.ops.hybrid.fct_mha.default, (q, k, v, in_w, None, out_w, None, 2))
+    out, saved = torch.ops.hybrid.fct_mha(q.detach(), k.detach(), v.detach(), in_w.detach(), in_b.detach(), out_w.detach(), out_b.detach(), 2)
+    _opcheck(torch.ops.hybrid.fct_mha_bwd.default, (torch.randn_like(out), q.detach(), k.detach(), v.detach(), in_w.detach(), out_w.detach(), saved, 2, True, True))
+    _opcheck(torch.ops.hybrid.fct_add.default, (x, torch.randn_like(x).requires_grad_(True)))
+    for mode in (0, 2):
+        _opcheck(torch.ops.hybrid.fct_resample.default, (x, mode))
+        yr = torch.ops.hybrid.fct_resample(x.detach(), mode)
+        _opcheck(torch.ops.hybrid.fct_resample_bwd.default, (torch.randn_like(yr), x.detach(), mode))
+    _opcheck(torch.ops.hybrid.fct_resample.default, (x.detach(), 1))
+    x2 = torch.randn(2, 8, 8, 5, device=dev, requires_grad=True)
+    _opcheck(torch.ops.hybrid.fct_concat.default, (x, x2))
+    _opcheck(torch.ops.hybrid.fct_concat_bwd.default, (torch.randn(2, 8, 8, 13, device=dev), 8, 5))
+    _opcheck(torch.ops.hybrid.fct_dropout.default, (x, 0.3, 77))
+    _opcheck(torch.ops.hybrid.fct_dropout.default, (x, 0.3, 77, torch.tensor([3], dtype=torch.int64, device=dev)))
+    pred, true = torch.rand(2, 1, 8, 8, device=dev, requires_grad=True), (torch.rand(2, 1, 8, 8, device=dev) > 0.5).float()
+    _opcheck(torch.ops.hybrid.dice_loss.default, (pred, true, 1.0))
+    _opcheck(torch.ops.hybrid.dice_loss_bwd.default, (torch.ones((), device=dev), pred.detach(), true, 1.0))
