@@ -833,6 +833,7 @@ _CLIP_GRAD_MSG = ("the first conv stage does not compute a gradient for its inpu
 class _NchwToNhwcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dt, cp):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (dt, x.shape[1])
         with _below_autograd():
             return torch.ops.hybrid.nchw_to_nhwc(x, dt, cp)
@@ -845,6 +846,7 @@ class _NchwToNhwcFn(torch.autograd.Function):
 class _NhwcToNchwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dt, C):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (dt, x.shape[3])
         with _below_autograd():
             return torch.ops.hybrid.nhwc_to_nchw(x, dt, C)
@@ -857,6 +859,7 @@ class _NhwcToNchwFn(torch.autograd.Function):
 class _CastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dt, to_t):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (dt, not to_t)
         with _below_autograd():
             return torch.ops.hybrid.cast(x, dt, to_t)
@@ -869,6 +872,7 @@ class _CastFn(torch.autograd.Function):
 class _ConvStageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, rm, rv, training, momentum, eps, dt, first):
+        ctx.set_materialize_grads(False)
         if first and ctx.needs_input_grad[0]:
             raise RuntimeError(_CLIP_GRAD_MSG)
         with _below_autograd():
@@ -889,6 +893,7 @@ class _ConvStageFn(torch.autograd.Function):
 class _TokenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dt):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             tok, feat = torch.ops.hybrid.token(x, weight, bias, dt)
         ctx.save_for_backward(feat, weight)
@@ -907,6 +912,7 @@ class _TokenFn(torch.autograd.Function):
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *params):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             out, saved = torch.ops.hybrid.encoder(x, mask, params, dt, hid, L, H, attn_p, layer_p, seed, seed_inc)
         ctx.save_for_backward(saved, *params) if mask is None else ctx.save_for_backward(saved, mask, *params)
@@ -927,6 +933,7 @@ class _EncoderFn(torch.autograd.Function):
 class _MhaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_in, k_in, v_in, mask, dt, H, p_drop, seed, *params):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             out = torch.ops.hybrid.mha(q_in, k_in, v_in, mask, params, dt, H, p_drop, seed)
         if mask is None:
@@ -949,6 +956,7 @@ class _MhaFn(torch.autograd.Function):
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dt):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (bias is not None, dt)
         with _below_autograd():
@@ -965,6 +973,7 @@ class _HeadFn(torch.autograd.Function):
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(logits, target)
         with _below_autograd():
             return torch.ops.hybrid.cross_entropy(logits, target)
@@ -978,6 +987,7 @@ class _CrossEntropyFn(torch.autograd.Function):
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, S, training, momentum, eps, dt, *tensors):
+        ctx.set_materialize_grads(False)
         if ctx.needs_input_grad[0]:
             raise RuntimeError(_CLIP_GRAD_MSG)
         weights, gammas, betas, rms, rvs = (tensors[i * S:(i + 1) * S] for i in range(5))
@@ -1003,6 +1013,7 @@ class _BackboneFn(torch.autograd.Function):
 class _TemporalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, token_w, token_b, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *enc_params):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             logits, feat, saved, enc_out = torch.ops.hybrid.temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H,
                                                                       attn_p, layer_p, seed, seed_inc)
@@ -1126,6 +1137,7 @@ def fct_conv_bwd_fake(dy, x, weight, saved, has_bias, need_dx, dilation, act):
 class _FctConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dilation, act):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             y, z = torch.ops.hybrid.fct_conv(x, weight, bias, dilation, act)
         ctx.save_for_backward(x, weight, z if act == ACT_GELU else y)
@@ -1186,6 +1198,7 @@ def fct_qkv_proj_bwd_fake(x, weights, biases, ln_weights, dqs, eps):
 class _FctQkvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps, *t):                               # t = 3 weights, 3 biases, 3 LN weights, 3 LN biases
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             out = torch.ops.hybrid.fct_qkv_proj(x, t[0:3], t[3:6], t[6:9], t[9:12], eps)
         ctx.save_for_backward(x, *t[0:9])
@@ -1234,6 +1247,7 @@ def fct_ln_bwd_fake(dy, x, weight, eps):
 class _FctLnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, weight)
         ctx.eps = eps
         with _below_autograd():
@@ -1294,6 +1308,7 @@ def fct_mha_bwd_fake(dout, q, k, v, in_w, out_w, saved, heads, has_in_b, has_out
 class _FctMhaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, in_w, in_b, out_w, out_b, heads):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             out, saved = torch.ops.hybrid.fct_mha(q, k, v, in_w, in_b, out_w, out_b, heads)
         ctx.save_for_backward(q, k, v, in_w, out_w, saved)
@@ -1326,6 +1341,7 @@ def fct_add_fake(a, b):
 class _FctAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
         with _below_autograd():
             return torch.ops.hybrid.fct_add(a, b)
 
@@ -1365,6 +1381,7 @@ def fct_resample_bwd_fake(dy, x, mode):
 class _FctResampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mode):
+        ctx.set_materialize_grads(False)
         if mode == 1 and ctx.needs_input_grad[0]:
             raise NotImplementedError("AvgPool2d is applied to the input frames only (FCT.py:238-240): no backward")
         ctx.save_for_backward(x)
@@ -1408,6 +1425,7 @@ def fct_concat_bwd_fake(dy, Ca, Cb):
 class _FctConcatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (a.shape[-1], b.shape[-1])
         with _below_autograd():
             return torch.ops.hybrid.fct_concat(a, b)
@@ -1432,6 +1450,7 @@ def fct_dropout_fake(x, p, seed, seed_inc=None):
 class _FctDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed, seed_inc):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (p, seed)
         ctx.seed_inc = seed_inc
         with _below_autograd():
@@ -1478,6 +1497,7 @@ def dice_loss_bwd_fake(dloss, pred, true, smooth):
 class _DiceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, true, smooth):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(pred, true)
         ctx.smooth = smooth
         with _below_autograd():
