@@ -25,6 +25,9 @@ while the CNN backbone's backward graph executes:
     graph B: backward of the conv stages                                   -> their gradients in the "backbone" bucket
     all_reduce(backbone bucket, async); wait both
     graph C: AdamW over all parameters (gradients = views of the buckets), step counter += 1
+
+With one rank there is nothing to exchange and no bucket: the gradient tensors produced under capture live at fixed addresses in
+the graphs' private pool, so they are bound to ``p.grad`` once and AdamW reads them in place (saves the two pack copies, ~25 us).
 """
 import torch
 import torch.distributed as dist
@@ -49,8 +52,8 @@ class GraphedTrainStep:
         self.b_params = [p for p in model.backbone_parameters() if p.requires_grad]
         if len(self.t_params) + len(self.b_params) != sum(1 for p in model.parameters() if p.requires_grad):
             raise RuntimeError("model has trainable parameters outside its backbone and temporal parts")
-        self.t_bucket, self.t_views = self._bucket(self.t_params)
-        self.b_bucket, self.b_views = self._bucket(self.b_params)
+        self.t_bucket, self.t_views = self._bucket(self.t_params) if self.world > 1 else (None, None)
+        self.b_bucket, self.b_views = self._bucket(self.b_params) if self.world > 1 else (None, None)
         self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl" and hasattr(dist.ReduceOp, "AVG")
         if self.world > 1:                                     # same start on every rank
             with torch.no_grad():
@@ -59,8 +62,9 @@ class GraphedTrainStep:
 
         ops.set_step_counter(self.counter)
         optimizer.set_step_counter(self.counter)
-        for p, v in zip(self.t_params + self.b_params, self.t_views + self.b_views):
-            p.grad = v                                         # AdamW reads the (all-reduced) buckets in place
+        if self.world > 1:
+            for p, v in zip(self.t_params + self.b_params, self.t_views + self.b_views):
+                p.grad = v                                     # AdamW reads the (all-reduced) buckets in place
         # warm-up on a side stream (lazy initialisation, allocator steady state), then capture
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -91,19 +95,26 @@ class GraphedTrainStep:
         return flat, views
 
     # ---- the three pieces (identical code runs eagerly in the warm-up and under capture) -------------------------------
-    def _piece_a(self):
+    def _piece_a(self, bind=True):
         h, B = self.model.forward_backbone(self.x)
         logits = self.model.forward_temporal(h, B, self.mask)
         loss = self.criterion(logits, self.y)
         grads = torch.autograd.grad(loss, [h] + self.t_params)
         self._h, self._gh = h, grads[0]
-        torch._foreach_copy_(self.t_views, list(grads[1:]))
+        self._deliver(self.t_params, self.t_views, grads[1:], bind)
         self.loss = loss.detach()
 
-    def _piece_b(self):
+    def _piece_b(self, bind=True):
         grads = torch.autograd.grad(self._h, self.b_params, grad_outputs=self._gh)
-        torch._foreach_copy_(self.b_views, list(grads))
+        self._deliver(self.b_params, self.b_views, grads, bind)
         self._h = self._gh = None
+
+    def _deliver(self, params, views, grads, bind):
+        if views is not None:
+            torch._foreach_copy_(views, list(grads))
+        elif bind:                                             # one rank: the captured gradient tensors themselves (static addresses)
+            for p, g in zip(params, grads):
+                p.grad = g
 
     def _piece_c(self):
         if self.world > 1 and not self._avg:
@@ -153,8 +164,8 @@ class GraphedTrainStep:
 
     def eager_fwd_bwd(self):
         """The same forward + backward issued launch by launch (for per-kernel event timing, which needs live launches)."""
-        self._piece_a()
-        self._piece_b()
+        self._piece_a(bind=False)
+        self._piece_b(bind=False)
         return self.loss
 
     def steps_done(self):
