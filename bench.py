@@ -155,7 +155,7 @@ def conv_kernel_table(args, dt_code, tdt, dev):
                          None, None, wsf.data_ptr(), wsf.numel(), st)
 
             def s1b():
-                lib.call("hyb_convstage_bwd", dt_code, 1, dp.data_ptr(), x.data_ptr(), None, w.data_ptr(), gamma.data_ptr(), ss.data_ptr(), mi.data_ptr(),
+                lib.call("hyb_convstage_bwd", dt_code, 1, dp.data_ptr(), x.data_ptr(), None, None, w.data_ptr(), gamma.data_ptr(), ss.data_ptr(), mi.data_ptr(),
                          1, N, H, H, ci, 0, co, co, None, dw.data_ptr(), dg.data_ptr(), db.data_ptr(), None, wsb.data_ptr(), wsb.numel(), st)
             rows.append(dict(kernel="stage1_fwd (conv+stats, conv+bn+relu+pool)", composite=True, flops=2 * flops,
                              bytes=float(2 * N * ci * H * H * 4 + N * (H // 2) ** 2 * co * es), ms=timeit(s1f)))

@@ -128,8 +128,10 @@ int hyb_bn_relu_pool_fwd(int dtype, const void* y, const float* scale_shift, voi
  *                             gamma*invstd*dy                                        (eval)
  *          and writes dgamma[Co] = sum dy*xhat, dbeta[Co] = sum dy. */
 size_t hyb_bn_bwd_reduce_workspace(int Cop);
-int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* scale_shift,
-                                const float* mean_invstd, float* sums, float* partials /* hyb_bn_bwd_reduce_workspace bytes */,
+int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y,
+                                const void* pooled /* NULL, or the forward's pooled output [N,H/2,W/2,Cop]: the sums are then formed from it
+                                                      (xhat at the arg-max = (pooled - beta)/gamma where pooled > 0) without reading y */,
+                                const float* scale_shift, const float* mean_invstd, float* sums, float* partials /* hyb_bn_bwd_reduce_workspace bytes */,
                                 float* dgamma /* [Co] or NULL */, float* dbeta /* [Co] or NULL */,
                                 int N, int H, int W, int Co, int Cop, void* stream);
 int hyb_bn_relu_pool_bwd_dx(int dtype, const void* dpooled, const void* y, const float* scale_shift,
@@ -159,6 +161,7 @@ int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, 
 long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop);
 size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop);
 int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw,
+                      const void* pooled /* NULL, or the stage's forward output (see hyb_bn_relu_pool_bwd_reduce) */,
                       const float* weight, const float* gamma, const float* scale_shift,
                       const float* mean_invstd, int training,
                       int N, int H, int W, int Ci, int Cip, int Co, int Cop,
@@ -260,7 +263,8 @@ int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x,
                      float momentum, float eps, int N, int H, int W, void* const* outs, void* workspace, size_t workspace_bytes,
                      void* stream);
 size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* channels, int N, int H, int W);
-int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const float* x, const float* const* params,
+int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last,
+                     const void* pooled_last /* NULL, or the last stage's forward output */, const float* x, const float* const* params,
                      const void* const* saved, int training, int N, int H, int W, float* const* grads, void* workspace,
                      size_t workspace_bytes, void* stream);
 

@@ -53,8 +53,10 @@ def test_opcheck_convstage(dt, first, training):
     assert out[5].shape == ((2, co) if training else (0,))
     dp = torch.randn_like(out[0])
     # (the backward operators are first-order only: every input is passed detached)
-    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1].detach(), w.detach(), g.detach(), out[2].detach(), out[3].detach(),
+    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1].detach(), None, w.detach(), g.detach(), out[2].detach(), out[3].detach(),
                                                       out[4].detach(), training, dt, first))
+    _opcheck(torch.ops.hybrid.convstage_bwd.default, (dp, x.detach(), out[1].detach(), out[0].detach(), w.detach(), g.detach(), out[2].detach(),
+                                                      out[3].detach(), out[4].detach(), training, dt, first))
 
 
 @pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
@@ -190,7 +192,7 @@ def test_opcheck_model_level_operators(dt):
     saved = []
     for s in range(2):
         saved += [st[s][0].detach(), (st[s - 1][1] if s > 0 else st[s][0]).detach(), st[s][2].detach(), st[s][3].detach(), st[s][4].detach()]
-    _opcheck(torch.ops.hybrid.backbone_bwd.default, (torch.randn_like(res[0]).detach(), x, [w.detach() for w in ws], [g.detach() for g in gs], saved, True, dt))
+    _opcheck(torch.ops.hybrid.backbone_bwd.default, (torch.randn_like(res[0]).detach(), res[0].detach(), x, [w.detach() for w in ws], [g.detach() for g in gs], saved, True, dt))
     # temporal part: B=4, S=8 keeps the saved blob free of alignment gaps (see test_opcheck_encoder_and_mha)
     B, S, D, Hid, L, H = 4, 8, 32, 64, 2, 2
     enc = P().TransformerEncoder(D, Hid, L, H, 0.1).cuda()

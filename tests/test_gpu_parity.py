@@ -133,6 +133,30 @@ def test_conv_stage_matches_oracle(mode, ci, co, n, h, w, training):
         assert int(bn_h.num_batches_tracked) == int(bn_r.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_conv_stage_with_zero_and_tiny_gammas(training):
+    """The backward's per-channel sums are formed from the pooled output as (pooled - beta) / gamma; a channel whose gamma is exactly
+    zero cannot be inverted and takes the raw-conv-output path for its 8-channel group -- both must give the oracle's gradients."""
+    ref, hip = _stage_pair(32, 64, "enc1", "fp32")
+    with torch.no_grad():
+        for m in (ref, hip):
+            m.enc1norm1.weight[3] = 0.0
+            m.enc1norm1.weight[17] = 1e-3
+            m.enc1norm1.weight[40] = -2e-3
+            m.enc1norm1.bias[3] = 0.4                 # gamma = 0, beta > 0: every window passes the ReLU with the value beta
+    ref.train(training); hip.train(training)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 32, 12, 20, generator=g)
+    r = torch.randn(2, 64, 6, 10, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr) * r).sum().backward()
+    xh = x.cuda().requires_grad_(True)
+    yh = hip(xh)
+    (yh * r.cuda()).sum().backward()
+    check_param_grads(hip, ref, 1e-3, "fp32")
+    check(xh.grad, xr.grad, 1e-3, "dx", "fp32")
+
+
 def test_golden_g1_reference_block_on_hip():
     """The vectors captured from the reference's UNet._block(3,8,'enc1')[:3] + MaxPool2d (tests/golden/make_golden.py)."""
     g = load_gold("g1_unet_block_stage.npz")

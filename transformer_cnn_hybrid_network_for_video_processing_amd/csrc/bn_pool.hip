@@ -170,6 +170,100 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_kernel(const T* _
     }
 }
 
+// pass 1, fast form: the same two sums from the stage's OUTPUT instead of its full-resolution raw conv output.  The routed gradient is
+// non-zero only at a window's arg-max and only if the ReLU passed, i.e. iff pooled > 0; there pooled = scale*y_sel + shift, so
+// xhat_sel = (y_sel - mean)*invstd = (pooled - beta)/gamma with beta = shift + mean*scale, 1/gamma = invstd/scale: one quarter-resolution
+// read (pooled) replaces four full-resolution ones (2.5x fewer bytes for the pass).  The inversion carries pooled's storage rounding
+// u*|pooled| into xhat as u*|xhat + beta/gamma| (the raw-output path carries u*|xhat + mean/sigma|), so it is taken only where
+// |beta/gamma| <= 4 (bf16 storage) / 1024 (fp32); an octet holding any other channel -- including gamma == 0, which cannot be inverted
+// at all -- takes the raw-output path.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_pooled_kernel(const T* __restrict__ dp, const T* __restrict__ pooled,
+                                                                             const T* __restrict__ y, const float* __restrict__ ss,
+                                                                             const float* __restrict__ mi, float* __restrict__ sums, int N, int H,
+                                                                             int W, int Cop) {
+    extern __shared__ float red[];
+    const int OCT = Cop >> 3, Ho = H >> 1, Wo = W >> 1;
+    const int nthr = row_threads(OCT);
+    if ((int)threadIdx.x < nthr) {
+        const int oc = threadIdx.x % OCT;
+        float sc[8], sh[8], mean[8], inv[8], bta[8], rg[8], a1[8], a2[8];
+        bool singular = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = ss[oc * 8 + j]; sh[j] = ss[Cop + oc * 8 + j];
+            mean[j] = mi[oc * 8 + j]; inv[j] = mi[Cop + oc * 8 + j];
+            bta[j] = fmaf(mean[j], sc[j], sh[j]);
+            rg[j] = inv[j] / sc[j];
+            singular = singular || !(fabsf(bta[j] * rg[j]) <= (sizeof(T) == 2 ? 4.f : 1024.f) && fabsf(rg[j]) <= 3.0e38f);
+            a1[j] = 0.f; a2[j] = 0.f;
+        }
+        const int rows = N * Ho, rowlen = Wo * OCT;
+        if (!singular) {
+            // dp and pooled are flat streams of 8-channel groups; group i belongs to octet i % OCT, and the stride nthr * gridDim keeps a
+            // thread on its octet.  Four groups per iteration: eight 16-byte loads in flight per lane.
+            const long long total = (long long)rows * rowlen, stride = (long long)nthr * gridDim.x;
+            long long i = (long long)blockIdx.x * nthr + threadIdx.x;
+            auto accum = [&](const Vec8<T>& pv, const Vec8<T>& g) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = pv.get(j);
+                    const float dy = v > 0.f ? g.get(j) : 0.f;
+                    a1[j] += dy;
+                    a2[j] += dy * (v - bta[j]) * rg[j];
+                }
+            };
+            for (; i + 3 * stride < total; i += 4 * stride) {
+                Vec8<T> pv[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { pv[u].load(pooled + (i + u * stride) * 8); g[u].load(dp + (i + u * stride) * 8); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accum(pv[u], g[u]);
+            }
+            for (; i < total; i += stride) {
+                Vec8<T> pv, g;
+                pv.load(pooled + i * 8); g.load(dp + i * 8);
+                accum(pv, g);
+            }
+        } else {
+            for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+                const long long rbase = (long long)row * Wo * Cop;
+                const int n = row / Ho, ho = row - n * Ho;
+                const T* yrow = y + ((long long)(n * H + 2 * ho) * W) * Cop;
+                for (int idx = threadIdx.x; idx < rowlen; idx += nthr) {
+                    const int wo = idx / OCT;
+                    const T* src = yrow + (long long)(2 * wo) * Cop + oc * 8;
+                    Vec8<T> a, b, c, d, g;
+                    a.load(src); b.load(src + Cop); c.load(src + (long long)W * Cop); d.load(src + (long long)W * Cop + Cop);
+                    g.load(dp + rbase + (long long)wo * Cop + oc * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y0 = a.get(j), y1 = b.get(j), y2 = c.get(j), y3 = d.get(j);
+                        float vmax;
+                        const int am = argmax4(y0 * sc[j] + sh[j], y1 * sc[j] + sh[j], y2 * sc[j] + sh[j], y3 * sc[j] + sh[j], vmax);
+                        const float ysel = am == 0 ? y0 : am == 1 ? y1 : am == 2 ? y2 : y3;
+                        const float dy = vmax > 0.f ? g.get(j) : 0.f;
+                        a1[j] += dy;
+                        a2[j] += dy * (ysel - mean[j]) * inv[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[threadIdx.x * 16 + j] = a1[j];
+            red[threadIdx.x * 16 + 8 + j] = a2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) {
+        const int which = i / Cop, ch = i % Cop, o8 = ch >> 3, j = ch & 7;
+        float acc = 0.f;
+        for (int t = o8; t < nthr; t += OCT) acc += red[t * 16 + which * 8 + j];
+        sums[(long long)blockIdx.x * 2 * Cop + i] = acc;
+    }
+}
+
 // pass 2: dense gradient w.r.t. the raw conv output.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_dx_kernel(const T* __restrict__ dp, const T* __restrict__ y,
@@ -370,7 +464,7 @@ extern "C" int hyb_profile_clear(void) {
     return 0;
 }
 
-extern "C" int hyb_abi_version(void) { return 3; }
+extern "C" int hyb_abi_version(void) { return 4; }
 extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
 extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }
 
@@ -409,12 +503,18 @@ extern "C" int hyb_bn_stats_finalize(const float* stats_partials, int G, const f
     return 0;
 }
 
-extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const float* ss, const float* mi, float* sums,
-                                           float* partials, float* dgamma, float* dbeta, int N, int H, int W, int Co, int Cop, void* stream) {
+extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const void* y, const void* pooled, const float* ss, const float* mi,
+                                           float* sums, float* partials, float* dgamma, float* dbeta, int N, int H, int W, int Co, int Cop,
+                                           void* stream) {
     HYB_CHECK_ARG(dpooled && y && ss && mi && sums && partials && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0 && Cop / 8 <= 256);
     const int grid = row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 256 * 16 * sizeof(float);
+    if (pooled) {
+        HYB_DISPATCH_T(dtype,
+            hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_pooled_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)pooled, (const float*)y, ss, mi, partials, N, H, W, Cop),
+            hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_pooled_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)pooled, (const bf16*)y, ss, mi, partials, N, H, W, Cop));
+    } else
     HYB_DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)dpooled, (const float*)y, ss, mi, partials, N, H, W, Cop),
         hipLaunchKernelGGL(bn_relu_pool_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), lds, st, (const bf16*)dpooled, (const bf16*)y, ss, mi, partials, N, H, W, Cop));

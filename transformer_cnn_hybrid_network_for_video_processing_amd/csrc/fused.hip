@@ -56,7 +56,8 @@ extern "C" size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* c
     return al256(stage_ws) + 2 * al256(dx_bytes);
 }
 
-extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const float* x, const float* const* params,
+extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const void* pooled_last, const float* x,
+                                const float* const* params,
                                 const void* const* saved, int training, int N, int H, int W, float* const* grads, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(stages >= 1 && stages <= 16 && channels && dpooled_last && x && params && saved && grads && workspace && N > 0);
@@ -82,7 +83,8 @@ extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, cons
         float* const* G = grads + (size_t)s * 3;                 // dweight, dgamma, dbeta
         const int Ci = channels[s], Co = channels[s + 1];
         void* dx = s == 0 ? nullptr : dxbuf[s & 1];
-        HYB_TRY(hyb_convstage_bwd(dtype, s == 0, dp, s == 0 ? (const void*)x : S[1], S[0], P[0], P[1], (const float*)S[2], (const float*)S[3],
+        const void* pooled = s + 1 < stages ? saved[(size_t)(s + 1) * 5 + 1] : pooled_last;      // a stage's output is the next stage's saved input
+        HYB_TRY(hyb_convstage_bwd(dtype, s == 0, dp, s == 0 ? (const void*)x : S[1], S[0], pooled, P[0], P[1], (const float*)S[2], (const float*)S[3],
                                   training, N, hs[s], wsz[s], Ci, s == 0 ? 0 : padc(Ci), Co, padc(Co), dx, G[0], G[1], G[2], S[4], ws, al256(stage_ws),
                                   stream));
         dp = dx;

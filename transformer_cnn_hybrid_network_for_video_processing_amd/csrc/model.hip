@@ -136,7 +136,7 @@ extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H
     return b;
 }
 
-extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const float* weight,
+extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const void* pooled, const float* weight,
                                  const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
                                  int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
                                  const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream) {
@@ -158,7 +158,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     void* slabs = ws;
     const size_t slab_bytes = hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop);
     const long long count = (long long)N * H * W;
-    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
+    HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, pooled, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
     // dense BN/ReLU/pool backward is computed inside the wgrad tile staging; the tile is also written once (dyraw) for dgrad
     HYB_TRY(hyb_conv3x3_wgrad_fused(dtype, x, y_raw, dpooled, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dweight, N, H, W,
                                     Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream));

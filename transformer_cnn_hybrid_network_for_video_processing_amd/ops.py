@@ -281,8 +281,8 @@ def convstage_fake(x, weight, gamma, beta, running_mean, running_var, training, 
             x.new_empty((2, Co) if training and track else (0,), dtype=torch.float32))
 
 
-def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, weight: Tensor, gamma: Tensor, scale_shift: Tensor, mean_invstd: Tensor,
-                     packed_bwd: Tensor, training: bool, dt: int, first: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, pooled: Optional[Tensor], weight: Tensor, gamma: Tensor, scale_shift: Tensor,
+                     mean_invstd: Tensor, packed_bwd: Tensor, training: bool, dt: int, first: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """-> (dx, dweight, dgamma, dbeta); dx is an empty placeholder for the first stage (the clip tensor gets no gradient)."""
     _require_cuda(dpooled, x)
     N, H, W, Ci, Cip, Co, Cop = _convstage_dims(x, weight, first)
@@ -293,14 +293,15 @@ def convstage_bwd_op(dpooled: Tensor, x: Tensor, y_raw: Tensor, weight: Tensor, 
     dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
     dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
     ws = _ws(_query("hyb_convstage_bwd_workspace", dt, int(first), N, H, W, Cip, Cop), dev)
-    lib.call("hyb_convstage_bwd", dt, int(first), dpooled.data_ptr(), x.data_ptr(), None if first else y_raw.data_ptr(), weight.contiguous().data_ptr(),
+    lib.call("hyb_convstage_bwd", dt, int(first), dpooled.data_ptr(), x.data_ptr(), None if first else y_raw.data_ptr(),
+             None if (first or pooled is None) else pooled.contiguous().data_ptr(), weight.contiguous().data_ptr(),
              gamma.contiguous().data_ptr(), scale_shift.data_ptr(), mean_invstd.data_ptr(), int(training), N, H, W, Ci, Cip, Co, Cop,
              None if first else dx.data_ptr(), dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
              packed_bwd.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     return dx, dw, dgamma, dbeta
 
 
-def convstage_bwd_fake(dpooled, x, y_raw, weight, gamma, scale_shift, mean_invstd, packed_bwd, training, dt, first):
+def convstage_bwd_fake(dpooled, x, y_raw, pooled, weight, gamma, scale_shift, mean_invstd, packed_bwd, training, dt, first):
     N, H, W, Ci, Cip, Co, Cop = _convstage_dims(x, weight, first)
     return (x.new_empty((0,) if first else (N, H, W, Cip), dtype=_TORCH_DTYPE[dt]), torch.empty_like(weight, memory_format=torch.contiguous_format),
             x.new_empty((Co,), dtype=torch.float32), x.new_empty((Co,), dtype=torch.float32))
@@ -696,8 +697,8 @@ def _backbone_unpack(res, S):
     return out
 
 
-def backbone_bwd_op(dpooled: Tensor, x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], saved: Sequence[Tensor], training: bool,
-                    dt: int) -> List[Tensor]:
+def backbone_bwd_op(dpooled: Tensor, pooled: Tensor, x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], saved: Sequence[Tensor],
+                    training: bool, dt: int) -> List[Tensor]:
     """saved: per stage (y_raw, stage input [placeholder for stage 0], scale_shift, mean_invstd, packed_bwd).
     -> per stage (dweight, dgamma, dbeta), flattened."""
     _require_cuda(dpooled, x)
@@ -716,12 +717,12 @@ def backbone_bwd_op(dpooled: Tensor, x: Tensor, weights: Sequence[Tensor], gamma
         sv = saved[5 * s:5 * s + 5]
         sptr += [None if s == 0 else sv[0].data_ptr(), None if s == 0 else sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), sv[4].data_ptr()]
     ws = _ws(_query("hyb_backbone_bwd_workspace", dt, S, tuple(chans), N, H, W), dev)
-    lib.call("hyb_backbone_bwd", dt, S, _int_array(chans), dpooled.data_ptr(), x.data_ptr(), ptr_array(pptr), ptr_array(sptr), int(training),
+    lib.call("hyb_backbone_bwd", dt, S, _int_array(chans), dpooled.data_ptr(), pooled.contiguous().data_ptr(), x.data_ptr(), ptr_array(pptr), ptr_array(sptr), int(training),
              N, H, W, ptr_array(gptr), ws.data_ptr(), ws.numel(), _stream())
     return grads
 
 
-def backbone_bwd_fake(dpooled, x, weights, gammas, saved, training, dt):
+def backbone_bwd_fake(dpooled, pooled, x, weights, gammas, saved, training, dt):
     res = []
     for w in weights:
         res += [torch.empty_like(w, memory_format=torch.contiguous_format), x.new_empty((w.shape[0],), dtype=torch.float32),
@@ -877,16 +878,16 @@ class _ConvStageFn(torch.autograd.Function):
             raise RuntimeError(_CLIP_GRAD_MSG)
         with _below_autograd():
             out = torch.ops.hybrid.convstage(x, weight, gamma, beta, rm, rv, training, momentum, eps, dt, first)
-        ctx.save_for_backward(x, out[1], weight, gamma, out[2], out[3], out[4])
+        ctx.save_for_backward(x, out[1], weight, gamma, out[2], out[3], out[4], out[0])
         ctx.cfg = (training, dt, first)
         ctx.mark_non_differentiable(*out[1:])
         return out
 
     @staticmethod
     def backward(ctx, dpooled, *unused):
-        x, y_raw, weight, gamma, ss, mi, pk = ctx.saved_tensors
+        x, y_raw, weight, gamma, ss, mi, pk, pooled = ctx.saved_tensors
         training, dt, first = ctx.cfg
-        dx, dw, dgamma, dbeta = torch.ops.hybrid.convstage_bwd(dpooled, x, y_raw, weight, gamma, ss, mi, pk, training, dt, first)
+        dx, dw, dgamma, dbeta = torch.ops.hybrid.convstage_bwd(dpooled, x, y_raw, pooled, weight, gamma, ss, mi, pk, training, dt, first)
         return (None if first else dx, dw, dgamma, dbeta) + (None,) * 7
 
 
@@ -997,7 +998,7 @@ class _BackboneFn(torch.autograd.Function):
         saved = []
         for s in range(S):
             saved += [st[s][0], (st[s - 1][1] if s > 0 else st[s][0]), st[s][2], st[s][3], st[s][4]]
-        ctx.save_for_backward(x, *weights, *gammas, *saved)
+        ctx.save_for_backward(x, res[0], *weights, *gammas, *saved)
         ctx.cfg = (S, training, dt)
         ctx.mark_non_differentiable(*res[1:])
         return tuple(res)
@@ -1006,7 +1007,7 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dpooled, *unused):
         S, training, dt = ctx.cfg
         t = ctx.saved_tensors
-        g = torch.ops.hybrid.backbone_bwd(dpooled, t[0], t[1:1 + S], t[1 + S:1 + 2 * S], t[1 + 2 * S:], training, dt)
+        g = torch.ops.hybrid.backbone_bwd(dpooled, t[1], t[0], t[2:2 + S], t[2 + S:2 + 2 * S], t[2 + 2 * S:], training, dt)
         return (None,) * 6 + tuple(g[0::3]) + tuple(g[1::3]) + tuple(g[2::3]) + (None,) * (2 * S)
 
 
@@ -1041,7 +1042,7 @@ _define("nhwc_to_nchw", "(Tensor x, int dt, int C) -> Tensor", nhwc_to_nchw_op, 
 _define("cast", "(Tensor x, int dt, bool to_t) -> Tensor", cast_op, cast_fake, _CastFn.apply)
 _define("convstage", "(Tensor x, Tensor weight, Tensor gamma, Tensor beta, Tensor? running_mean, Tensor? running_var, bool training, float momentum, "
         "float eps, int dt, bool first) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", convstage_op, convstage_fake, _ConvStageFn.apply)
-_define("convstage_bwd", "(Tensor dpooled, Tensor x, Tensor y_raw, Tensor weight, Tensor gamma, Tensor scale_shift, Tensor mean_invstd, "
+_define("convstage_bwd", "(Tensor dpooled, Tensor x, Tensor y_raw, Tensor? pooled, Tensor weight, Tensor gamma, Tensor scale_shift, Tensor mean_invstd, "
         "Tensor packed_bwd, bool training, int dt, bool first) -> (Tensor, Tensor, Tensor, Tensor)", convstage_bwd_op, convstage_bwd_fake)
 _define("token", "(Tensor x, Tensor weight, Tensor? bias, int dt) -> (Tensor, Tensor)", token_op, token_fake, _TokenFn.apply)
 _define("token_bwd", "(Tensor dtok, Tensor feat, Tensor weight, int Hh, int Ww, bool has_bias, int dt) -> (Tensor, Tensor, Tensor)", token_bwd_op,
@@ -1065,7 +1066,7 @@ _define("backbone", "(Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] beta
         "float momentum, float eps, int dt) -> Tensor[]", backbone_op, backbone_fake,
         lambda x, ws, gs, bs, rms, rvs, training, momentum, eps, dt: list(_BackboneFn.apply(x, len(ws), training, momentum, eps, dt, *ws, *gs, *bs,
                                                                                           *rms, *rvs)))
-_define("backbone_bwd", "(Tensor dpooled, Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] saved, bool training, int dt) -> Tensor[]",
+_define("backbone_bwd", "(Tensor dpooled, Tensor pooled, Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] saved, bool training, int dt) -> Tensor[]",
         backbone_bwd_op, backbone_bwd_fake)
 _define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_params, Tensor head_w, Tensor head_b, Tensor? mask, int B, int dt, "
         "int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> (Tensor, Tensor, Tensor, Tensor)", temporal_op,
