@@ -9,7 +9,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhybrid_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "fct.hip", "fct_bwd.hip", "optim.hip"]
+SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "fct.hip", "fct_bwd.hip", "optim.hip"]
+
+
+# Per-file compiler flags.  conv_first_wave.hip: MFMA results in VGPRs instead of AGPRs -- its kernels are bound by VALU instruction issue
+# and every accumulator value is consumed by vector instructions, which cannot read AGPRs (one v_accvgpr_read per value otherwise).
+FILE_FLAGS = {"conv_first_wave.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():
@@ -36,7 +41,7 @@ def build(force=False, verbose=False, jobs=4):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

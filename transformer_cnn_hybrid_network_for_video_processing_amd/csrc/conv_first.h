@@ -1,0 +1,33 @@
+// Shared declarations of the stage-1 kernels (conv_first.hip: block-level kernels and the backward pass; conv_first_wave.hip: the
+// wave-private forward passes, compiled with MFMA results in VGPRs).
+#pragma once
+#include "hyb_common.h"
+
+constexpr int S1_KP = 64;                      // padded K of the packed first-layer weights
+
+// 4 channels of one pixel as one 8-byte (bf16) / 16-byte (fp32) LDS access
+template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
+
+struct S1Args {
+    const float* x;          // [N,Ci,H,W] fp32
+    const void* wp;          // packed weights T [Cop][64], k = tap*4 + c
+    const void* wp2;         // the same weights in the wave-private kernels' K order (s1w_pack_kernel)
+    const float* ss;         // scale/shift [2][Cop]
+    const float* mi;         // mean/invstd [2][Cop]
+    const float* gamma;      // [Co]
+    const float* sums;       // [2][Cop] (sum dy, sum dy*xhat)
+    const void* dp;          // dpooled NHWC T [N,H/2,W/2,Cop]
+    void* pooled;            // pooled NHWC T
+    float* part;             // per-workgroup partial rows (stats / sums / wgrad slabs)
+    int N, H, W, Ci, Co, Cop;
+    int training;
+    float inv_count;
+    int tilesX, tilesY, numTiles;
+    float inv_tpi, inv_tx;   // 1 / (tilesX*tilesY), 1 / tilesX: tile -> (n, ty, tx) without integer division
+    int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
+};
+
+// conv_first_wave.hip
+int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, hipStream_t st);
+int hyb_stage1w_pass(int dtype, int mode /* 0 statistics, 1 apply + pool */, const S1Args& a, int& grid_x /* in: wanted workgroups; out: launched */,
+                     hipStream_t st);

@@ -12,20 +12,18 @@
 // to T and expanded into an im2col matrix P[pixel][k = tap*4 + c] in LDS; P rows feed the conv MFMA (k contiguous) and
 // P columns feed the wgrad MFMA through transposed LDS reads, so no scalar gathers are needed.
 #include <stdlib.h>
-#include "hyb_common.h"
+#include "conv_first.h"
 
 namespace {
 
 constexpr int S1_TH = 8, S1_TW = 32, S1_HW = S1_TW + 2, S1_HH = S1_TH + 2, S1_HP = S1_HH * S1_HW;   // halo 10 x 34 = 340 pixels
 constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
-constexpr int S1_KP = 64, S1_PS = S1_KP + 8;   // padded K and P row stride (elements)
+constexpr int S1_PS = S1_KP + 8;               // P row stride (elements); S1_KP (padded K) is in conv_first.h
 constexpr int S1_MAXPART = 1024;               // workgroups (= partial statistics rows) of the forward passes: four per CU (512 measured 40% slower)
 constexpr int S1_BWD_PART = 512;               // workgroups (= partial rows) of the one-pass backward
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;
 
-// 4 channels of one pixel as one 8-byte (bf16) / 16-byte (fp32) LDS access
-template <typename T> struct alignas(sizeof(T) * 4) Quad { T v[4]; };
 
 __device__ __forceinline__ void tr_frag_s1(Frag<bf16>& f, const bf16* base, int stride, int second, int lane) {
     const int qq = (lane & 15) >> 2, pp = lane & 3;
@@ -44,23 +42,6 @@ __device__ __forceinline__ void tr_frag_s1(Frag<float>& f, const float* base, in
     }
 }
 
-struct S1Args {
-    const float* x;          // [N,Ci,H,W] fp32
-    const void* wp;          // packed weights T [Cop][64], k = tap*4 + c
-    const float* ss;         // scale/shift [2][Cop]
-    const float* mi;         // mean/invstd [2][Cop]
-    const float* gamma;      // [Co]
-    const float* sums;       // [2][Cop] (sum dy, sum dy*xhat)
-    const void* dp;          // dpooled NHWC T [N,H/2,W/2,Cop]
-    void* pooled;            // pooled NHWC T
-    float* part;             // per-workgroup partial rows (stats / sums / wgrad slabs)
-    int N, H, W, Ci, Co, Cop;
-    int training;
-    float inv_count;
-    int tilesX, tilesY, numTiles;
-    float inv_tpi, inv_tx;   // 1 / (tilesX*tilesY), 1 / tilesX: tile -> (n, ty, tx) without integer division
-    int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
-};
 
 constexpr int S1_IW = S1_TW + 8;               // image row in LDS: columns tx0-4 .. tx0+35 (aligned float4 segments)
 constexpr int S1_IMG = S1_HH * S1_IW;          // 400 pixels x 4 channels
@@ -506,7 +487,7 @@ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // ---- internal entry points used by hyb_convstage_{fwd,bwd} when first = 1 ----------------------------------------------
 size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * 2 * Cop * 4);
+    return 2 * al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * 2 * Cop * 4);
 }
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -527,13 +508,24 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = packed_out ? (T*)packed_out : (T*)ws; ws += al256((size_t)Cop * 64 * es);      // packed weights are kept for backward when asked
+    T* wp2 = (T*)ws;                             ws += al256((size_t)Cop * 64 * es);      // the wave-private kernels' K order
     float* stats = (float*)ws;                   ws += al256(2 * (size_t)Cop * 4);
     float* part = (float*)ws;
     const long long total = (long long)Cop * 64;
-    hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
-    HYB_LAUNCH_CHECK();
+    static const int wave_env = getenv("HYB_S1_WAVE") ? atoi(getenv("HYB_S1_WAVE")) : 1;          // second-generation forward passes (A/B)
+    // they address x and pooled with 32-bit buffer offsets and load aligned float4 row segments
+    const bool vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const bool wave_private = wave_env && vec_ok && (long long)N * Ci * H * W * 4 < (1ll << 32) &&
+                              (long long)N * (H / 2) * (W / 2) * Cop * (long long)es < (1ll << 32);
+    if (packed_out || !wave_private) {                       // k = tap*4 + c: the block-level kernels and the backward pass
+        hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
+        HYB_LAUNCH_CHECK();
+    }
+    if (wave_private) {
+        if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, st)) return e;
+    }
     S1Args a{};
-    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.pooled = pooled; a.part = part;
+    a.x = x; a.wp = wp; a.wp2 = wp2; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.pooled = pooled; a.part = part;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
     a.inv_tpi = 1.0f / (float)(a.tilesX * a.tilesY); a.inv_tx = 1.0f / (float)a.tilesX;
@@ -542,10 +534,11 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     a.numTiles = (int)numTiles;
     const int gx = s1_grid(numTiles);
     int rc;
+    int gx_rows = gx;                                      // partial statistics rows actually written
     if (training) {
-        rc = s1_dispatch<T, 0>(a, gx, st);
+        rc = wave_private ? hyb_stage1w_pass(dtype, 0, a, gx_rows, st) : s1_dispatch<T, 0>(a, gx, st);
         if (rc) return rc;
-        rc = hyb_bn_stats_finalize(part, gx, gamma, beta, running_mean, running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop,
+        rc = hyb_bn_stats_finalize(part, gx_rows, gamma, beta, running_mean, running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop,
                                    scale_shift, mean_invstd, running_out, (void*)st);
     } else {
         rc = hyb_bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, 0, momentum, eps, (long long)N * H * W, Co, Cop,
@@ -557,7 +550,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     static const int apply_wgs = getenv("HYB_S1_APPLY_WGS") ? atoi(getenv("HYB_S1_APPLY_WGS")) : 2048;
     int gx1 = apply_wgs > 0 ? apply_wgs : gx;
     if (gx1 > numTiles) gx1 = (int)numTiles;
-    return s1_dispatch<T, 1>(a, gx1, st);
+    return wave_private ? hyb_stage1w_pass(dtype, 1, a, gx1, st) : s1_dispatch<T, 1>(a, gx1, st);
 }
 
 template <typename T>

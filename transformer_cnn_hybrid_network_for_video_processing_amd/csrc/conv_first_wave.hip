@@ -1,0 +1,306 @@
+// Stage 1, wave-private forward passes (see conv_first.hip for the stage's overall scheme and the block-level kernels).
+// This file is compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py): every accumulator value is consumed by vector instructions,
+// which cannot read AGPRs, and the kernels are bound by VALU instruction issue -- one v_accvgpr_read per value otherwise.
+#include <stdlib.h>
+#include "conv_first.h"
+
+namespace {
+
+// ---- wave-private forward passes (second generation of MODE 0 / MODE 1) ---------------------------------------------------------
+// Measured on the block-level kernel above: it is bound by VALU *instruction issue*, not by memory, LDS or the matrix cores -- a timing
+// build with loads, LDS traffic, MFMAs and epilogue all removed still took 2/3 of the time (tile decode with float reciprocals, 64-bit
+// address arithmetic and bounds tests per channel, accumulator copies).  This version is built around the instruction count:
+//   * every WAVE is independent (no barrier in the loop): it owns a run of 8x16-pixel blocks, stages its own 10x24-pixel halo image
+//     (double-buffered in its private LDS slice; the next block's fp32 rows are in flight in registers meanwhile);
+//   * block coordinates advance by scalar increments; global addresses are "uniform block offset + per-lane constant" through buffer
+//     loads/stores (1 VALU add per block; lanes outside the image get an out-of-range offset and the hardware returns zeros / drops the
+//     store), so padding and ragged edges cost no per-channel tests;
+//   * LDS fragment addresses are per-lane constants (+ immediates); the k-step-1 fragment reuses the registers of the k-step-0 one
+//     (its extra K slots meet zero weights); the 2x2 max + ReLU is two v_max3, statistics use packed fp32 adds/fmas.
+// Same fragment scheme, K order, packed weights, partial-row layout and results as the block-level kernel, which remains the path for
+// row strides that are not a multiple of 4 floats and for tensors of 4 GiB and more (32-bit buffer offsets).
+constexpr int S1W_BW = 16;                       // block width: two 8x8 sub-blocks side by side
+constexpr int S1W_R = 28;                        // LDS image row stride in pixels (24 used); 2 rows = 448 B = 48 banks past a multiple of 64
+constexpr int S1W_ROWS = 10;
+constexpr int S1W_IMG = S1W_ROWS * S1W_R * 4;    // elements per buffer
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void s1w_store8(__amdgpu_buffer_rsrc_t rs, unsigned voff, const Vec8<bf16>& o) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.v), rs, voff, 0, 0);
+}
+__device__ __forceinline__ void s1w_store8(__amdgpu_buffer_rsrc_t rs, unsigned voff, const Vec8<float>& o) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.a), rs, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.b), rs, voff, 16, 0);      // soffset is outside the range check: an out-of-range voff stays out of range
+}
+
+template <typename T, int NT, int MODE, int CI /* 3: RGB frames (no per-channel tests); 0: any Ci <= 4 */>
+__global__ __launch_bounds__(256) void stage1w_kernel(S1Args a) {
+    static_assert(MODE == 0 || MODE == 1, "forward passes only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T* img0 = reinterpret_cast<T*>(smem_raw) + wave * (2 * S1W_IMG);           // this wave's two image buffers
+    float* wgstat = reinterpret_cast<float*>(reinterpret_cast<T*>(smem_raw) + 4 * 2 * S1W_IMG);      // [4][2][NT*16] (mode 0)
+    const int p = lane & 15, q = lane >> 4, wy = p >> 2, wx = p & 3;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int H = a.H, W = a.W, Ci = a.Ci, Cop = a.Cop;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const T* wp = (const T*)a.wp2;                                             // the wave kernels' own K order (s1w_pack_kernel)
+
+    Frag<T> w0[NT], w1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const T* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
+        frag_load(w0[t], row);
+        frag_load(w1[t], row + 32);
+    }
+    f32x2 c_sc[NT][2], c_sh[NT][2];
+    if (MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = co_base + q * (NT * 4) + t * 4 + r;
+                c_sc[t][r >> 1][r & 1] = a.ss[ch]; c_sh[t][r >> 1][r & 1] = a.ss[Cop + ch];
+            }
+    }
+    f32x2 acc1[NT][2], acc2[NT][2];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { acc1[t][h] = f32x2{0.f, 0.f}; acc2[t][h] = f32x2{0.f, 0.f}; }
+    }
+
+    // this wave's run of blocks (row-major inside an image: neighbours share halo columns in L2)
+    const int bx_n = a.tilesX, by_n = a.tilesY, bpi = bx_n * by_n;
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    const int chunk = (a.numTiles + nwaves - 1) / nwaves;
+    const int blk_begin = gw * chunk < a.numTiles ? gw * chunk : a.numTiles;
+    const int blk_end = blk_begin + chunk < a.numTiles ? blk_begin + chunk : a.numTiles;
+    const int nblk = blk_end - blk_begin;
+
+    // ---- per-lane constants ----
+    // halo: lane u < 60 owns (row = u / 6, segment = u % 6) = 4 consecutive pixels x up to 4 channels
+    const int hrow = lane / 6, hseg = lane - hrow * 6;
+    const bool hlane = lane < 60;
+    const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);                         // bytes from the block's halo origin
+    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);                      // element offset of this lane's 4 pixels in an image buffer
+    const unsigned plane = (unsigned)(H * W) * 4u;                                          // channel plane in bytes
+    const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
+    const unsigned OOB = 0xFFFFFFF0u;
+    // fragment reads (K order of s1w_pack_kernel): a lane's 8 K elements are TWO HORIZONTALLY ADJACENT pixels x 4 channels, i.e. one
+    // 16-byte run of the image -- a single ds_read2_b64 straight into the MFMA operand registers, no assembly moves.
+    //   k-step 0: q = 0,1,2 -> taps (q,0),(q,1);  q = 3 -> tap (0,2) + the pixel right of the window (zero weights)
+    //   k-step 1: q = 0 -> tap (1,2), q = 1 -> tap (2,2) (+ zero-weight neighbours); q = 2,3 read q = 1's address (zero weights)
+    const int f_k0 = ((2 * wy + (q < 3 ? q : 0)) * S1W_R + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
+    const int f_k1 = ((2 * wy + (q == 0 ? 1 : 2)) * S1W_R + 2 * wx + 3 + 2) * 4;
+    // pooled store (MODE 1): bytes from the block's first window, for sub-block 0
+    const unsigned po_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
+    const __amdgpu_buffer_rsrc_t prs = hyb_rsrc(MODE == 1 ? a.pooled : (void*)a.x, MODE == 1 ? (unsigned)((long long)a.N * Ho * Wo * Cop * (int)sizeof(T)) : 16u);
+
+    // block coordinates: scalar counters, advanced by increments (one division per wave, here)
+    int n_c = blk_begin / bpi, by_c, bx_c;
+    { const int rem = blk_begin - n_c * bpi; by_c = rem / bx_n; bx_c = rem - by_c * bx_n; }
+    n_c = __builtin_amdgcn_readfirstlane(n_c); by_c = __builtin_amdgcn_readfirstlane(by_c); bx_c = __builtin_amdgcn_readfirstlane(bx_c);
+    int n_n = n_c, by_n_ = by_c, bx_n_ = bx_c;                                              // coordinates of the block being prefetched
+    auto advance = [&](int& n, int& by, int& bx) {
+        ++bx;
+        if (bx == bx_n) { bx = 0; ++by; if (by == by_n) { by = 0; ++n; } }
+    };
+
+    f32x4 pf[4];
+    auto prefetch = [&](int n, int by, int bx) {
+        const int row0 = by * 8 - 1, col0 = bx * S1W_BW - 4;
+        const unsigned boff = (unsigned)((((long long)n * Ci * H + row0) * W + col0) * 4);  // wraps for the (masked) negative corner
+        const bool ok = hlane && (unsigned)(row0 + hrow) < (unsigned)H && (unsigned)(col0 + 4 * hseg) <= (unsigned)(W - 4);
+        const unsigned voff = ok ? ld_lane + boff : OOB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (CI ? c < CI : c < Ci) pf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * plane, 0));
+            else pf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](T* img) {
+        if (hlane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Quad<T> qv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                *reinterpret_cast<Quad<T>*>(img + st_lds + i * 4) = qv;
+            }
+        }
+    };
+    int cur = 0;
+    if (nblk > 0) { prefetch(n_c, by_c, bx_c); stage(img0); advance(n_n, by_n_, bx_n_); }
+
+    for (int it = 0; it < nblk; ++it) {
+        const T* img = img0 + cur * S1W_IMG;
+        const bool more = it + 1 < nblk;
+        if (more) prefetch(n_n, by_n_, bx_n_);                        // in flight under this block's work
+        const bool inside = (by_c * 8 + 8 <= H) && (bx_c * S1W_BW + S1W_BW <= W);          // uniform: no ragged edge in this block
+        // the fragments of window positions jx = 0 and jx = 1 overlap by one pixel; left alone the compiler reads every pixel once and
+        // assembles the second fragment with register moves -- VALU work on the critical resource to save LDS bandwidth that is idle.
+        // An opaque copy of the offset keeps the two reads separate: each fragment is one ds_read2_b64 into its operand registers.
+        int fx0[2] = {f_k0, f_k0 + 4}, fx1[2] = {f_k1, f_k1 + 4};
+        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]));
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            f32x4 acc[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int joff = ((j >> 1) * S1W_R + 8 * sb) * 4;
+                const int f_k0 = fx0[j & 1], f_k1 = fx1[j & 1];
+                Frag<T> b0, b1;
+                {
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + f_k0 + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + f_k0 + joff + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { b0.v[c] = lo.v[c]; b0.v[4 + c] = hi.v[c]; }
+                }
+                {
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + f_k1 + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + f_k1 + joff + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { b1.v[c] = lo.v[c]; b1.v[4 + c] = hi.v[c]; }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[j][t] = mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    acc[j][t] = mma32(w1[t], b1, acc[j][t]);
+                }
+            }
+            if (MODE == 0) {
+                if (inside) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x2 v = f32x2{acc[j][t][2 * h], acc[j][t][2 * h + 1]};
+                                acc1[t][h] += v;
+                                acc2[t][h] = v * v + acc2[t][h];
+                            }
+                } else {
+                    const int gy0 = by_c * 8 + 2 * wy, gx0 = bx_c * S1W_BW + 8 * sb + 2 * wx;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m = ((gy0 + (j >> 1)) < H && (gx0 + (j & 1)) < W) ? 1.f : 0.f;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x2 v = f32x2{acc[j][t][2 * h] * m, acc[j][t][2 * h + 1] * m};
+                                acc1[t][h] += v;
+                                acc2[t][h] = v * v + acc2[t][h];
+                            }
+                    }
+                }
+            }
+            if (MODE == 1) {
+                const int oy0 = by_c * 4, ox0 = bx_c * (S1W_BW / 2) + 4 * sb;              // first window of this sub-block
+                const unsigned pbase = (unsigned)((((long long)n_c * Ho + oy0) * Wo + ox0) * Cop * (int)sizeof(T));
+                const bool win_ok = inside || ((oy0 + wy) < Ho && (ox0 + wx) < Wo);
+                const unsigned pvoff = win_ok ? po_lane + pbase : OOB;
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    Vec8<T> o;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const int t = h8 * 2 + (e2 >> 1), h = e2 & 1;
+                        const f32x2 sc = c_sc[t][h], sh = c_sh[t][h];
+                        f32x2 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = f32x2{acc[j][t][2 * h], acc[j][t][2 * h + 1]} * sc + sh;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float m = __builtin_fmaxf(__builtin_fmaxf(v[0][u], v[1][u]), v[2][u]);                 // v_max3
+                            o.set(e2 * 2 + u, __builtin_fmaxf(__builtin_fmaxf(m, v[3][u]), 0.f));                        // v_max3 with the ReLU's zero
+                        }
+                    }
+                    s1w_store8(prs, win_ok ? pvoff + h8 * 8 * (unsigned)sizeof(T) : OOB, o);
+                }
+            }
+        }
+        if (more) { stage(img0 + (cur ^ 1) * S1W_IMG); advance(n_n, by_n_, bx_n_); }      // the other buffer: this block's reads are all issued
+        advance(n_c, by_c, bx_c);
+        cur ^= 1;
+    }
+
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = group16_sum(acc1[t][r >> 1][r & 1]), s2 = group16_sum(acc2[t][r >> 1][r & 1]);
+                if (p == 0) {
+                    wgstat[(wave * 2 + 0) * (NT * 16) + q * (NT * 4) + t * 4 + r] = s1;
+                    wgstat[(wave * 2 + 1) * (NT * 16) + q * (NT * 4) + t * 4 + r] = s2;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 16; i += 256) {
+            const int which = i / (NT * 16), cl = i % (NT * 16);
+            const float v = (wgstat[(0 * 2 + which) * (NT * 16) + cl] + wgstat[(1 * 2 + which) * (NT * 16) + cl]) +
+                            (wgstat[(2 * 2 + which) * (NT * 16) + cl] + wgstat[(3 * 2 + which) * (NT * 16) + cl]);
+            a.part[((long long)blockIdx.x * 2 + which) * Cop + co_base + cl] = v;
+        }
+    }
+}
+
+// packed first-layer weights for the wave-private forward kernels: T [Cop][64], k = slot*4 + c with the slot -> tap map below
+// (slot pairs (2q, 2q+1) of a k-step are horizontally adjacent pixels; -1 = zero weights)
+template <typename T>
+__global__ void s1w_pack_kernel(const float* __restrict__ w, T* __restrict__ wp2, int Co, int Ci, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % 64), co = (int)(i / 64);
+    const int slot = k >> 2, c = k & 3;
+    //                  k-step 0: (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (0,2)  -    k-step 1: (1,2) -  (2,2) -   -   -   -   -
+    const int tap_of_slot[16] = {0, 1, 3, 4, 6, 7, 2, -1, 5, -1, 8, -1, -1, -1, -1, -1};
+    const int tap = tap_of_slot[slot];
+    float v = 0.f;
+    if (co < Co && tap >= 0 && c < Ci) v = w[((long long)co * Ci + c) * 9 + tap];
+    wp2[i] = from_f32<T>(v);
+}
+
+template <typename T, int NT, int MODE>
+int s1w_launch(S1Args a, int grid_x, hipStream_t st) {
+    const size_t lds = (size_t)4 * 2 * S1W_IMG * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
+    dim3 grid(grid_x, a.Cop / (NT * 16));
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 3>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 0>), grid, dim3(256), lds, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+// the wave-private forward passes work on 8x8 blocks: tilesX/tilesY/numTiles of `a` are re-derived for that block size
+template <typename T, int MODE>
+int s1w_dispatch(S1Args a, int& grid_x /* in: wanted workgroups; out: launched (= partial rows of MODE 0) */, hipStream_t st) {
+    a.tilesX = hyb_cdiv(a.W, S1W_BW); a.tilesY = hyb_cdiv(a.H, 8);
+    const long long nb = (long long)a.N * a.tilesX * a.tilesY;
+    if (nb >= (1ll << 30)) return HYB_E_ARG;
+    a.numTiles = (int)nb;
+    if ((long long)grid_x * 4 > nb) grid_x = (int)((nb + 3) / 4);
+    if (a.Cop % 64 == 0) return s1w_launch<T, 4, MODE>(a, grid_x, st);
+    return s1w_launch<T, 2, MODE>(a, grid_x, st);
+}
+
+}  // namespace
+
+int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, hipStream_t st) {
+    const long long total = (long long)Cop * 64;
+    if (dtype == HYB_F32) hipLaunchKernelGGL(s1w_pack_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, (float*)wp2, Co, Ci, total);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(s1w_pack_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, (bf16*)wp2, Co, Ci, total);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+int hyb_stage1w_pass(int dtype, int mode, const S1Args& a, int& grid_x, hipStream_t st) {
+    if (dtype == HYB_F32) return mode == 0 ? s1w_dispatch<float, 0>(a, grid_x, st) : s1w_dispatch<float, 1>(a, grid_x, st);
+    if (dtype == HYB_BF16) return mode == 0 ? s1w_dispatch<bf16, 0>(a, grid_x, st) : s1w_dispatch<bf16, 1>(a, grid_x, st);
+    return HYB_E_ARG;
+}
