@@ -29,5 +29,6 @@ struct S1Args {
 
 // conv_first_wave.hip
 int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, hipStream_t st);
+int hyb_stage1w_bwd(int dtype, S1Args a, int& grid_x /* in: wanted workgroups; out: launched = partial rows */, hipStream_t st);
 int hyb_stage1w_pass(int dtype, int mode /* 0 statistics, 1 apply + pool */, const S1Args& a, int& grid_x /* in: wanted workgroups; out: launched */,
                      hipStream_t st);

@@ -19,7 +19,8 @@ namespace {
 constexpr int S1_TH = 8, S1_TW = 32, S1_HW = S1_TW + 2, S1_HH = S1_TH + 2, S1_HP = S1_HH * S1_HW;   // halo 10 x 34 = 340 pixels
 constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
 constexpr int S1_PS = S1_KP + 8;               // P row stride (elements); S1_KP (padded K) is in conv_first.h
-constexpr int S1_MAXPART = 1024;               // workgroups (= partial statistics rows) of the forward passes: four per CU (512 measured 40% slower)
+constexpr int S1_MAXPART = 2048;               // most workgroups (= partial statistics rows) of the statistics pass (workspace size)
+constexpr int S1_FWD_WGS = 1024;               // its default grid: four workgroups per CU (512 measured 40% slower)
 constexpr int S1_BWD_PART = 512;               // workgroups (= partial rows) of the one-pass backward
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;
@@ -491,12 +492,13 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
 }
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 8) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
+    return 2 * al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 8) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
 }
 
 static int s1_grid(long long numTiles) {
-    static const int fwd_wgs = getenv("HYB_S1_FWD_WGS") ? atoi(getenv("HYB_S1_FWD_WGS")) : S1_MAXPART;         // <= S1_MAXPART (workspace)
+    static const int fwd_wgs = getenv("HYB_S1_FWD_WGS") ? atoi(getenv("HYB_S1_FWD_WGS")) : S1_FWD_WGS;
     long long g = numTiles < fwd_wgs ? numTiles : fwd_wgs;
+    if (g > S1_MAXPART) g = S1_MAXPART;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -507,8 +509,9 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
                         hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
-    T* wp = packed_out ? (T*)packed_out : (T*)ws; ws += al256((size_t)Cop * 64 * es);      // packed weights are kept for backward when asked
-    T* wp2 = (T*)ws;                             ws += al256((size_t)Cop * 64 * es);      // the wave-private kernels' K order
+    // packed weights in both K orders; kept for backward when asked (packed_out = [2][Cop][64])
+    T* wp = packed_out ? (T*)packed_out : (T*)ws;                       ws += al256((size_t)Cop * 64 * es);
+    T* wp2 = packed_out ? (T*)packed_out + (size_t)Cop * 64 : (T*)ws;   ws += al256((size_t)Cop * 64 * es);
     float* stats = (float*)ws;                   ws += al256(2 * (size_t)Cop * 4);
     float* part = (float*)ws;
     const long long total = (long long)Cop * 64;
@@ -521,7 +524,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
         hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
         HYB_LAUNCH_CHECK();
     }
-    if (wave_private) {
+    if (wave_private || packed_out) {
         if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, st)) return e;
     }
     S1Args a{};
@@ -560,17 +563,25 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
+    T* wp2 = (T*)ws;                             ws += al256((size_t)Cop * 64 * es);
     double* sums = (double*)ws;                  ws += al256(((size_t)Cop * 48 + 2304) * 8);      // reduced row [S1][G], double
     float* part = (float*)ws;
+    // the wave-private kernel: 16-bit storage, aligned float4 row segments, no ragged 8x16 blocks, 32-bit buffer offsets
+    static const int wave_env = getenv("HYB_S1_WAVE_BWD") ? atoi(getenv("HYB_S1_WAVE_BWD")) : 1;
+    const bool wave_private = wave_env && sizeof(T) == 2 && (W % 16 == 0) && (H % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                              (long long)N * Ci * H * W * 4 < (1ll << 32) && (long long)N * (H / 2) * (W / 2) * Cop * (long long)es < (1ll << 32);
+    const int dtype = sizeof(T) == 2 ? HYB_BF16 : HYB_F32;
     if (packed_in) {
-        wp = (T*)packed_in;                      // packed by the forward pass
+        wp = (T*)packed_in;                      // packed by the forward pass: [2][Cop][64]
+        wp2 = (T*)packed_in + (size_t)Cop * 64;
     } else {
         const long long total = (long long)Cop * 64;
         hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
         HYB_LAUNCH_CHECK();
+        if (wave_private) { if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, st)) return e; }
     }
     S1Args a{};
-    a.x = x; a.wp = wp; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = nullptr; a.dp = dpooled; a.part = part;
+    a.x = x; a.wp = wp; a.wp2 = wp2; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = nullptr; a.dp = dpooled; a.part = part;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Cop = Cop; a.training = training;
     a.inv_count = 1.0f / (float)((long long)N * H * W);
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
@@ -583,7 +594,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     int gx = (int)(numTiles < bwd_wgs ? numTiles : bwd_wgs);
     if (gx < 1) gx = 1;
     const long long roww = (long long)Cop * 48 + 2304;
-    int rc = s1_dispatch<T, 4>(a, gx, st);
+    int rc = wave_private ? hyb_stage1w_bwd(dtype, a, gx, st) : s1_dispatch<T, 4>(a, gx, st);
     if (rc) return rc;
     hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(roww, 32)), dim3(256), 0, st, part, sums, gx, roww);
     HYB_LAUNCH_CHECK();

@@ -34,8 +34,14 @@ __device__ __forceinline__ void s1w_store8(__amdgpu_buffer_rsrc_t rs, unsigned v
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.b), rs, voff, 16, 0);      // soffset is outside the range check: an out-of-range voff stays out of range
 }
 
+#ifndef S1W_SB_UNROLL
+#define S1W_SB_UNROLL 2
+#endif
+#ifndef S1W_MIN_WAVES
+#define S1W_MIN_WAVES 1
+#endif
 template <typename T, int NT, int MODE, int CI /* 3: RGB frames (no per-channel tests); 0: any Ci <= 4 */>
-__global__ __launch_bounds__(256) void stage1w_kernel(S1Args a) {
+__global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 1) void stage1w_kernel(S1Args a) {
     static_assert(MODE == 0 || MODE == 1, "forward passes only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void stage1w_kernel(S1Args a) {
         // An opaque copy of the offset keeps the two reads separate: each fragment is one ds_read2_b64 into its operand registers.
         int fx0[2] = {f_k0, f_k0 + 4}, fx1[2] = {f_k1, f_k1 + 4};
         asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]));
-#pragma unroll
+#pragma unroll S1W_SB_UNROLL
         for (int sb = 0; sb < 2; ++sb) {
             f32x4 acc[4][NT];
 #pragma unroll
@@ -251,6 +257,288 @@ __global__ __launch_bounds__(256) void stage1w_kernel(S1Args a) {
     }
 }
 
+// ---- wave-private backward pass (MODE 4 of conv_first.hip, same mathematics and the same partial-row layout) ----------------------
+// Per 8x8 sub-block a wave: recomputes the conv (16 MFMAs), routes dpooled to the window arg-max behind the ReLU (dz), parks dz in its
+// LDS slice [pixel][channel] and accumulates  S1 += dz^T P  and the Gram matrix  G += P^T P  with pixels as the MFMA K dimension.
+// The im2col matrix P is never built: a transposing LDS read (ds_read_b64_tr_b16) whose per-lane address is "pixel + tap offset"
+// takes the 4 channels x 4 consecutive pixels block straight out of the halo IMAGE (k = tap*4 + c: the four K columns of one tap are
+// the pixel's channel quad); the ones column and the zero padding of K come from a 3-quad constant table.  Only for frames whose
+// height is a multiple of 8 and width a multiple of 16 (no ragged blocks: G must not see pixels outside the image); everything else
+// takes the block-level kernel.
+constexpr int S1B_CT = 16;                       // constant table elements: quad {1,0,0,0} (K column 36 = ones), two zero quads, pad
+
+template <typename T> struct S1BTr;
+template <> struct S1BTr<bf16> {
+    // lo/hi: byte-exact 8-byte rows supplied by this lane (see tr_frag in conv_first.hip): the hardware hands lane L column L & 15
+    static __device__ __forceinline__ void read(Frag<bf16>& f, const bf16* lo, const bf16* hi) {
+        typedef __attribute__((address_space(3))) bf16x4 lds_q;
+        const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_q*)lo);
+        const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_q*)hi);
+        f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+        f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    }
+};
+
+template <typename T, int NT, int CI>
+__global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int DS = NT * 16 + 8;                                            // dz row stride (elements): odd multiple of 16 bytes
+    constexpr int WAVE_EL = 2 * S1W_IMG + 64 * DS + S1B_CT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T* img0 = reinterpret_cast<T*>(smem_raw) + wave * WAVE_EL;
+    T* dyt = img0 + 2 * S1W_IMG;                                               // [64 pixels][DS]
+    T* ctab = dyt + 64 * DS;
+    const int p = lane & 15, q = lane >> 4, wy = p >> 2, wx = p & 3;
+    const int pp = lane & 3, qq = (lane & 15) >> 2;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int H = a.H, W = a.W, Ci = a.Ci, Cop = a.Cop;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const T* wp = (const T*)a.wp2;
+
+    if (lane < S1B_CT) ctab[lane] = from_f32<T>(lane == 0 ? 1.f : 0.f);
+    Frag<T> w0[NT], w1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const T* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
+        frag_load(w0[t], row);
+        frag_load(w1[t], row + 32);
+    }
+    f32x2 c_sc[NT][2], c_sh[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = co_base + q * (NT * 4) + t * 4 + r;
+            c_sc[t][r >> 1][r & 1] = a.ss[ch]; c_sh[t][r >> 1][r & 1] = a.ss[Cop + ch];
+        }
+    f32x4 wacc[3][NT], gacc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int bx_n = a.tilesX, by_n = a.tilesY, bpi = bx_n * by_n;
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    const int chunk = (a.numTiles + nwaves - 1) / nwaves;
+    const int blk_begin = gw * chunk < a.numTiles ? gw * chunk : a.numTiles;
+    const int blk_end = blk_begin + chunk < a.numTiles ? blk_begin + chunk : a.numTiles;
+    const int nblk = blk_end - blk_begin;
+
+    // ---- per-lane constants (see stage1w_kernel) ----
+    const int hrow = lane / 6, hseg = lane - hrow * 6;
+    const bool hlane = lane < 60;
+    const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);
+    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);
+    const unsigned plane = (unsigned)(H * W) * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
+    const __amdgpu_buffer_rsrc_t drs = hyb_rsrc(a.dp, (unsigned)((long long)a.N * Ho * Wo * Cop * (int)sizeof(T)));
+    const unsigned OOB = 0xFFFFFFF0u;
+    const int f_k0 = ((2 * wy + (q < 3 ? q : 0)) * S1W_R + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
+    const int f_k1 = ((2 * wy + (q == 0 ? 1 : 2)) * S1W_R + 2 * wx + 3 + 2) * 4;
+    const unsigned dp_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
+    // pixels-as-K operands.  K index i of a 32-pixel step = (row i / 8, column i % 8) of 4 rows; this lane group (q) holds i = 4q .. 4q+3
+    // (lo) and 16 + 4q .. (hi = two rows further down); within a 16-lane group lane (pp, qq) supplies pixel i + qq, K columns 4pp .. 4pp+3.
+    const int pix_lo = ((q >> 1) * S1W_R + 4 * (q & 1) + qq + 3) * 4;           // element offset of pixel (4q + qq) of step 0, tap (0,0)
+    int boff[3];                                                               // + tap offset of K tile kt (tap = 4 kt + pp), or the constant table
+    bool bconst[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tap = 4 * kt + pp;
+        bconst[kt] = tap >= 9;
+        boff[kt] = tap < 9 ? pix_lo + ((tap / 3) * S1W_R + tap % 3) * 4 : (tap - 9) * 4;
+    }
+    const int a_lo = (4 * q + qq) * DS + 4 * pp;                               // dz tile: pixel 4q + qq, channels 4pp .. (+ 16 c)
+
+    int n_c = blk_begin / bpi, by_c, bx_c;
+    { const int rem = blk_begin - n_c * bpi; by_c = rem / bx_n; bx_c = rem - by_c * bx_n; }
+    n_c = __builtin_amdgcn_readfirstlane(n_c); by_c = __builtin_amdgcn_readfirstlane(by_c); bx_c = __builtin_amdgcn_readfirstlane(bx_c);
+    int n_n = n_c, by_n_ = by_c, bx_n_ = bx_c;
+    auto advance = [&](int& n, int& by, int& bx) {
+        ++bx;
+        if (bx == bx_n) { bx = 0; ++by; if (by == by_n) { by = 0; ++n; } }
+    };
+    f32x4 pf[4];
+    Vec8<T> gpf[2][NT / 2];                                                    // dpooled of both sub-blocks, one block ahead
+    auto prefetch = [&](int n, int by, int bx) {
+        const int row0 = by * 8 - 1, col0 = bx * S1W_BW - 4;
+        const unsigned bo = (unsigned)((((long long)n * Ci * H + row0) * W + col0) * 4);
+        const bool ok = hlane && (unsigned)(row0 + hrow) < (unsigned)H && (unsigned)(col0 + 4 * hseg) <= (unsigned)(W - 4);
+        const unsigned voff = ok ? ld_lane + bo : OOB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (CI ? c < CI : c < Ci) pf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * plane, 0));
+            else pf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned dbase = (unsigned)((((long long)n * Ho + by * 4) * Wo + bx * (S1W_BW / 2)) * Cop * (int)sizeof(T)) + dp_lane;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) {
+                const unsigned off = dbase + (unsigned)((sb * 4 * Cop + h8 * 8) * (int)sizeof(T));
+                static_assert(sizeof(T) == 2, "16-bit storage only (transposing LDS reads)");
+                gpf[sb][h8] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+            }
+    };
+    auto stage = [&](T* img) {
+        if (hlane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Quad<T> qv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                *reinterpret_cast<Quad<T>*>(img + st_lds + i * 4) = qv;
+            }
+        }
+    };
+    int cur = 0;
+    if (nblk > 0) { prefetch(n_c, by_c, bx_c); stage(img0); advance(n_n, by_n_, bx_n_); }
+
+    for (int it = 0; it < nblk; ++it) {
+        const T* img = img0 + cur * S1W_IMG;
+        const bool more = it + 1 < nblk;
+        Vec8<T> gcur[2][NT / 2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) gcur[sb][h8] = gpf[sb][h8];
+        if (more) prefetch(n_n, by_n_, bx_n_);
+        int fx0[2] = {f_k0, f_k0 + 4}, fx1[2] = {f_k1, f_k1 + 4};
+        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]));
+#pragma unroll 1
+        for (int sb = 0; sb < 2; ++sb) {
+            // ---- conv of the 8x8 sub-block (as in the forward kernels)
+            f32x4 acc[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int joff = ((j >> 1) * S1W_R + 8 * sb) * 4;
+                Frag<T> b0, b1;
+                {
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx0[j & 1] + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx0[j & 1] + joff + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { b0.v[c] = lo.v[c]; b0.v[4 + c] = hi.v[c]; }
+                }
+                {
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx1[j & 1] + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx1[j & 1] + joff + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { b1.v[c] = lo.v[c]; b1.v[4 + c] = hi.v[c]; }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[j][t] = mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    acc[j][t] = mma32(w1[t], b1, acc[j][t]);
+                }
+            }
+            // ---- route dpooled to the first maximum of each window (torch's scan order) behind the ReLU; park dz [pixel][channel]
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) {
+                const Vec8<T> g = sb == 0 ? gcur[0][h8] : gcur[1][h8];
+                Vec8<T> o[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int t = h8 * 2 + (e2 >> 1), h = e2 & 1;
+                    const f32x2 sc = c_sc[t][h], sh = c_sh[t][h];
+                    f32x2 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = f32x2{acc[j][t][2 * h], acc[j][t][2 * h + 1]} * sc + sh;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = e2 * 2 + u;
+                        const float m = __builtin_fmaxf(__builtin_fmaxf(v[0][u], v[1][u]), __builtin_fmaxf(v[2][u], v[3][u]));
+                        const float dy = m > 0.f ? g.get(e) : 0.f;
+                        const bool e0 = v[0][u] == m, e1 = v[1][u] == m, e2b = v[2][u] == m;
+                        o[0].set(e, e0 ? dy : 0.f);
+                        o[1].set(e, (!e0 && e1) ? dy : 0.f);
+                        o[2].set(e, (!e0 && !e1 && e2b) ? dy : 0.f);
+                        o[3].set(e, (!e0 && !e1 && !e2b) ? dy : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pix = (2 * wy + (j >> 1)) * 8 + 2 * wx + (j & 1);
+                    o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
+                }
+            }
+            // ---- S1[co][k] += dz^T P and G += P^T P over the sub-block's 64 pixels (two K steps of 32 pixels = 4 rows x 8)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> af[NT], bf[3];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const T* lo = dyt + ks * 32 * DS + a_lo + c * 16;
+                    S1BTr<T>::read(af[c], lo, lo + 16 * DS);
+                }
+                const int pstep = (4 * ks * S1W_R + 8 * sb) * 4;                // rows 4 ks .., columns 8 sb .. of the image
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const T* lo = bconst[kt] ? ctab + boff[kt] : img + boff[kt] + pstep;
+                    const T* hi = bconst[kt] ? lo : lo + 2 * S1W_R * 4;
+                    S1BTr<T>::read(bf[kt], lo, hi);
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf[kt], wacc[kt][c]);
+                }
+                if (blockIdx.y == 0) {
+                    gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
+                    gacc[3] = mma32(bf[1], bf[1], gacc[3]); gacc[4] = mma32(bf[1], bf[2], gacc[4]); gacc[5] = mma32(bf[2], bf[2], gacc[5]);
+                }
+            }
+        }
+        if (more) { stage(img0 + (cur ^ 1) * S1W_IMG); advance(n_n, by_n_, bx_n_); }
+        advance(n_c, by_c, bx_c);
+        cur ^= 1;
+    }
+
+    // combine the 4 waves through LDS: row = [S1: Cop x 48][G: 48 x 48 (upper triangle tiles filled)] -- the block-level kernel's layout
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);                           // [4][NT*16*48 + 2304]
+    constexpr int RW = NT * 16 * 48 + 2304;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * RW + (c * 16 + 4 * q + r) * 48 + kt * 16 + p] = wacc[kt][c][r];
+    auto put_g = [&](int i, int gi, int gj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * RW + NT * 16 * 48 + (gi * 16 + 4 * q + r) * 48 + gj * 16 + p] = gacc[i][r];
+    };
+    put_g(0, 0, 0); put_g(1, 0, 1); put_g(2, 0, 2); put_g(3, 1, 1); put_g(4, 1, 2); put_g(5, 2, 2);
+    __syncthreads();
+    const long long roww = (long long)Cop * 48 + 2304;
+    float* out = a.part + (long long)blockIdx.x * roww;
+    for (int i = tid; i < NT * 16 * 48; i += 256)
+        out[(long long)co_base * 48 + i] = (red[i] + red[RW + i]) + (red[2 * RW + i] + red[3 * RW + i]);
+    if (blockIdx.y == 0) {
+        for (int i = tid; i < 2304; i += 256) {
+            const int gr = i / 48, gc = i % 48;
+            const int o = NT * 16 * 48 + i;
+            out[(long long)Cop * 48 + i] = (gr / 16 <= gc / 16) ? (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]) : 0.f;
+        }
+    }
+}
+
+template <typename T, int NT>
+int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
+    constexpr int DS = NT * 16 + 8;
+    size_t lds = (size_t)4 * (2 * S1W_IMG + 64 * DS + S1B_CT) * sizeof(T);
+    const size_t red = (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
+    if (red > lds) lds = red;
+    lds += 64;
+    dim3 grid(grid_x, a.Cop / (NT * 16));
+    if (lds > 64 * 1024) {
+        static HybAttrOnce once3, once0;
+        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_kernel<T, NT, 3> : (const void*)stage1w_bwd_kernel<T, NT, 0>, (int)lds)) return e;
+    }
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 3>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 0>), grid, dim3(256), lds, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
 // packed first-layer weights for the wave-private forward kernels: T [Cop][64], k = slot*4 + c with the slot -> tap map below
 // (slot pairs (2q, 2q+1) of a k-step are horizontally adjacent pixels; -1 = zero weights)
 template <typename T>
@@ -297,6 +585,19 @@ int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, 
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
+}
+
+// backward pass over 8x16 blocks; `a` as for the block-level MODE 4 launch (wp2 set); bf16 only (the transposing LDS read is a 16-bit
+// instruction): fp32 parity mode keeps the block-level kernel
+int hyb_stage1w_bwd(int dtype, S1Args a, int& grid_x, hipStream_t st) {
+    if (dtype != HYB_BF16) return HYB_E_ARG;
+    a.tilesX = hyb_cdiv(a.W, S1W_BW); a.tilesY = hyb_cdiv(a.H, 8);
+    const long long nb = (long long)a.N * a.tilesX * a.tilesY;
+    if (nb >= (1ll << 30)) return HYB_E_ARG;
+    a.numTiles = (int)nb;
+    if ((long long)grid_x * 4 > nb) grid_x = (int)((nb + 3) / 4);
+    if (a.Cop % 64 == 0) return s1w_bwd_launch<bf16, 4>(a, grid_x, st);
+    return s1w_bwd_launch<bf16, 2>(a, grid_x, st);
 }
 
 int hyb_stage1w_pass(int dtype, int mode, const S1Args& a, int& grid_x, hipStream_t st) {
