@@ -1,20 +1,32 @@
 #!/bin/bash
-# Round profile collection on the GPU box (run through gpurun): kernel-trace summaries of the bench command for configs 2/4/5, then the
-# two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) of config 2.  Output under gpurun_out/prof_<tag>/.
+# Round profile collection on the GPU box (run through gpurun): plain bench lines (configs 2 / 4 / 5, fp32, eager), kernel-trace summaries of
+# the bench command for configs 2/4/5, the two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) of config 2, the
+# attention micro-benchmark and the FCT bench.  Output under gpurun_out/prof_<tag>/; scripts/publish_profiles.py copies the summaries.
 set -e
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
+cd $REPO
+python3 bench.py --steps 100 --warmup 10 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python3 bench.py --eager --steps 100 --warmup 10 --no-cpu-baseline --no-roofline > $OUT/bench_c2_eager.json 2> $OUT/bench_c2_eager.err
+python3 bench.py --config 4 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+python3 bench.py --config 5 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+python3 bench.py --dtype fp32 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
+echo "bench lines done"
+python3 scripts/attn_microbench.py > $OUT/attention_microbench.json 2> $OUT/attention_microbench.err || true
+python3 scripts/fct_bench.py --cpu > $OUT/fct_bench.json 2> $OUT/fct_bench.err || true
+python3 scripts/s1_bench.py > $OUT/stage1_bench.json 2> /dev/null || true
+echo "micro benches done"
 cd /tmp && export TMPDIR=/tmp
 for C in 2 4 5; do
   STEPS=30; [ $C != 2 ] && STEPS=12
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c$C -o kt -- python3 $REPO/bench.py --config $C --steps $STEPS --warmup 5 --no-cpu-baseline > $OUT/bench_c${C}_under_rocprof.json 2> $OUT/kt_c$C.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_c$C -o kt -- python3 $REPO/bench.py --config $C --steps $STEPS --warmup 5 --no-cpu-baseline --no-pipeline --no-fwd-bwd-only --no-roofline > $OUT/bench_c${C}_under_rocprof.json 2> $OUT/kt_c$C.err
+  rm -f $OUT/kt_c$C/kt_kernel_trace.csv
   echo "kernel trace config $C done"
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-fwd-bwd-only --no-pipeline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $REPO/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-fwd-bwd-only --no-pipeline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
-find $OUT -name "*.csv" -size +20M -delete     # raw per-dispatch traces are too large to bring back; the stats summaries stay
-ls -la $OUT $OUT/*
+ls $OUT
