@@ -9,6 +9,7 @@
 //   LayerNorm over C, MaxPool2d(2) (gradient to the first maximum in scan order, like torch), Upsample x2 (sum of the 2x2 block),
 //   cat (split), DiceLoss, dropout (counter-based mask regenerated from the seed).
 #include <math.h>
+#include <stdlib.h>
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
@@ -145,6 +146,97 @@ __global__ __launch_bounds__(256) void sliced_wgrad_kernel(const float* __restri
                 const int n = n0 + wm * 32 + i * 16 + 4 * q + r;
                 if (n < Nn) out[(long long)n * K + k] = acc[i][j][r];
             }
+        }
+}
+// Second generation: no LDS staging and no transposition at all.  With the 4-deep fp32 MFMA both operands are read straight from
+// the row-major [pixel][feature] matrices: lane (m = lane & 15, kq = lane >> 4) holds dy[p0 + kq][n0 + m] and x[p0 + kq][k0 + m] --
+// 16 consecutive features of 4 consecutive pixels per wave-load, fully coalesced.  A block owns NTL x KTL 16x16 output tiles of
+// one pixel slice, its 4 waves interleave over the slice's 4-pixel groups and are combined in a fixed order at the end.  The bias
+// gradient (column sums of dy) is one more MFMA per n tile against a constant ones operand.
+template <int NTL, int KTL>
+__global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ part, float* __restrict__ cpart /* [S][Nn] or null */, long long P,
+                                                           int Nn, int K, int kgroups, int slice_rows) {
+    __shared__ __attribute__((aligned(16))) float red[NTL * KTL * 256 + NTL * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int kg = blockIdx.x % kgroups, ng = blockIdx.x / kgroups;
+    const int n0 = ng * (16 * NTL), k0 = kg * (16 * KTL);
+    const long long r_begin = (long long)blockIdx.y * slice_rows;
+    const long long r_end = r_begin + slice_rows < P ? r_begin + slice_rows : P;
+    const bool want_cs = cpart != nullptr && kg == 0;
+    bool nok[NTL], kok[KTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) nok[i] = n0 + 16 * i + m < Nn;
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) kok[j] = k0 + 16 * j + m < K;
+    f32x4 acc[NTL][KTL], accs[NTL];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* dyp = dy + n0 + m;
+    const float* xp = x + k0 + m;
+#pragma unroll 2
+    for (long long p0 = r_begin + 4 * wave; p0 < r_end; p0 += 16) {
+        const long long pix = p0 + kq;
+        const bool pok = pix < r_end;
+        float a[NTL], b[KTL];
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) a[i] = (pok && nok[i]) ? dyp[pix * lddy + 16 * i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < KTL; ++j) b[j] = (pok && kok[j]) ? xp[pix * ldx + 16 * j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+#pragma unroll
+            for (int j = 0; j < KTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (want_cs) accs[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], 1.0f, accs[i], 0, 0, 0);
+        }
+    }
+    // combine the four waves in a fixed order (wave 0 + 1 + 2 + 3): waves 1..3 park their tiles in LDS one after the other
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+#pragma unroll
+                for (int j = 0; j < KTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((i * KTL + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[NTL * KTL * 256 + (i * 4 + r) * 64 + lane] = accs[i][r];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+#pragma unroll
+                for (int j = 0; j < KTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * KTL + j) * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accs[i][r] += red[NTL * KTL * 256 + (i * 4 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wave != 0) return;
+    float* out = part + (long long)blockIdx.y * Nn * K;
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * i + 4 * kq + r;                 // accumulator row = A's row index
+            if (n >= Nn) continue;
+#pragma unroll
+            for (int j = 0; j < KTL; ++j) {
+                const int k = k0 + 16 * j + m;
+                if (k < K) out[(long long)n * K + k] = acc[i][j][r];
+            }
+            if (want_cs && m == 0) cpart[(long long)blockIdx.y * Nn + n] = accs[i][r];
         }
 }
 // out[i] (+)= sum_s part[s][i], fixed order
@@ -442,13 +534,41 @@ int dispatch_cpl(int C, int& LPP, F&& f) {
 
 // Internal + used by fct MHA backward: out[Nn][K] (+)= dy^T x over P pixel rows, through SLICE_ROWS-row partial slabs in `ws`
 size_t hyb_sliced_wgrad_workspace(long long P, int Nn, int K) { return al256((size_t)hyb_cdiv(P, SLICE_ROWS) * Nn * K * 4); }
-int hyb_sliced_wgrad(const float* dy, int lddy, const float* x, int ldx, float* out, long long P, int Nn, int K, int accumulate, void* ws,
-                     hipStream_t st) {
-    const int S = hyb_cdiv(P, SLICE_ROWS), tk = hyb_cdiv(K, 64), tn = hyb_cdiv(Nn, 64);
-    hipLaunchKernelGGL(sliced_wgrad_kernel, dim3(tk * tn, S), dim3(256), 0, st, dy, lddy, x, ldx, (float*)ws, P, Nn, K, tk, SLICE_ROWS);
+template <int NTL, int KTL>
+static void launch_direct_wgrad(const float* dy, int lddy, const float* x, int ldx, float* part, float* cpart, long long P, int Nn, int K, int S,
+                                hipStream_t st) {
+    const int kgroups = hyb_cdiv(K, 16 * KTL), ngroups = hyb_cdiv(Nn, 16 * NTL);
+    hipLaunchKernelGGL((direct_wgrad_kernel<NTL, KTL>), dim3(kgroups * ngroups, S), dim3(256), 0, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, kgroups,
+                       SLICE_ROWS);
+}
+// out[Nn][K] (+)= dy^T x over P rows; colsum (optional, with its own partial workspace cws of hyb_sliced_colsum_workspace bytes):
+// colsum[Nn] (+)= column sums of dy, formed inside the same launch
+int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, float* out, float* colsum, long long P, int Nn, int K, int accumulate,
+                        void* ws, void* cws, hipStream_t st) {
+    static const int legacy = getenv("HYB_FCT_WGRAD_V1") ? atoi(getenv("HYB_FCT_WGRAD_V1")) : 0;      // first-generation kernel (A/B)
+    const int S = hyb_cdiv(P, SLICE_ROWS);
+    float* cpart = colsum ? (float*)cws : nullptr;
+    if (legacy) {
+        const int tk = hyb_cdiv(K, 64), tn = hyb_cdiv(Nn, 64);
+        hipLaunchKernelGGL(sliced_wgrad_kernel, dim3(tk * tn, S), dim3(256), 0, st, dy, lddy, x, ldx, (float*)ws, P, Nn, K, tk, SLICE_ROWS);
+        if (colsum) hipLaunchKernelGGL(colsum_slice_kernel, dim3(S), dim3(256), 0, st, dy, lddy, cpart, P, Nn, SLICE_ROWS);
+    } else if (Nn <= 16) {
+        if (K <= 32) launch_direct_wgrad<1, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+        else if (K <= 64) launch_direct_wgrad<1, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+        else launch_direct_wgrad<1, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+    } else {
+        if (K <= 32) launch_direct_wgrad<2, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+        else if (K <= 64) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+        else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+    }
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid1((long long)Nn * K)), dim3(256), 0, st, (const float*)ws, out, S, (long long)Nn * K, accumulate);
+    if (colsum) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid1(Nn)), dim3(256), 0, st, (const float*)cpart, colsum, S, (long long)Nn, accumulate);
     HYB_LAUNCH_CHECK();
     return 0;
+}
+int hyb_sliced_wgrad(const float* dy, int lddy, const float* x, int ldx, float* out, long long P, int Nn, int K, int accumulate, void* ws,
+                     hipStream_t st) {
+    return hyb_sliced_wgrad_cs(dy, lddy, x, ldx, out, nullptr, P, Nn, K, accumulate, ws, nullptr, st);
 }
 size_t hyb_sliced_colsum_workspace(long long P, int C) { return al256((size_t)hyb_cdiv(P, SLICE_ROWS) * C * 4); }
 int hyb_sliced_colsum(const float* v, int ldv, float* out, long long P, int C, int accumulate, void* ws, hipStream_t st) {
@@ -502,8 +622,7 @@ extern "C" int hyb_fct_conv_bwd(const float* dy, const float* x, const float* w,
         }
         hipLaunchKernelGGL(im2col_b_kernel, dim3(grid1(P * Kp)), dim3(256), 0, st, x + off * Ci, col, P, H, W, Ci, Kp, dilation);
         HYB_LAUNCH_CHECK();
-        FCT_TRY(hyb_sliced_wgrad(dz, Co8, col, Kp, dwp, P, Co8, Kp, chunk > 0, ws_w, st));
-        if (db) FCT_TRY(hyb_sliced_colsum(dz, Co8, dbp, P, Co8, chunk > 0, ws_c, st));
+        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, col, Kp, dwp, db ? dbp : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
     }
     hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * 9)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, Kp);
     if (db) { hipError_t e = hipMemcpyAsync(db, dbp, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
@@ -707,8 +826,7 @@ extern "C" int hyb_fct_mha_bwd(const float* dout, const float* q, const float* k
     {   // out-projection: dA = dout Wout (padded), dWout = dout^T A, dbout = column sums of dout
         const void* As[1] = {dout}; const void* Bs[1] = {woutT}; void* Cs[1] = {dA};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, As, Bs, Cs, nullptr, 0, (int)M, Cp, C, C, C, Cp, 0, 0, st));
-        FCT_TRY(hyb_sliced_wgrad(dout, C, A, Cp, dwout, M, C, Cp, 0, ws_w, st));
-        if (dout_b) FCT_TRY(hyb_sliced_colsum(dout, C, dout_b, M, C, 0, ws_c, st));
+        FCT_TRY(hyb_sliced_wgrad_cs(dout, C, A, Cp, dwout, dout_b, M, C, Cp, 0, ws_w, ws_c, st));
     }
     FCT_TRY(hyb_flash_attention_bwd(HYB_F32, Q, K, V, A, dA, lse, delta, dQ, dK, dV, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st));
     {   // in-projection: d(inputs) = dQ Win (three GEMMs in one launch), dWin_j = dQ_j^T input_j, dbin_j = column sums
@@ -716,8 +834,7 @@ extern "C" int hyb_fct_mha_bwd(const float* dout, const float* q, const float* k
         FCT_TRY(hyb_gemm_nt(HYB_F32, 3, As, Bs, Cs, nullptr, 0, (int)M, C, Cp, Cp, Cp, C, 0, 0, st));
         const float* ins[3] = {q, k, v}; const float* ds[3] = {dQ, dK, dV};
         for (int j = 0; j < 3; ++j) {
-            FCT_TRY(hyb_sliced_wgrad(ds[j], Cp, ins[j], C, dwin + (size_t)j * Cp * C, M, Cp, C, 0, ws_w, st));
-            FCT_TRY(hyb_sliced_colsum(ds[j], Cp, dbin + (size_t)j * Cp, M, Cp, 0, ws_c, st));
+            FCT_TRY(hyb_sliced_wgrad_cs(ds[j], Cp, ins[j], C, dwin + (size_t)j * Cp * C, dbin + (size_t)j * Cp, M, Cp, C, 0, ws_w, ws_c, st));
         }
     }
     hipLaunchKernelGGL(mha_unpack_kernel, dim3(grid1((long long)3 * C * C + 3 * C + C * C)), dim3(256), 0, st, (const float*)dwin, (const float*)dbin,
