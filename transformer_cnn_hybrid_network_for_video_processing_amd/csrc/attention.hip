@@ -543,10 +543,25 @@ namespace {
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8_c;
 
-template <typename T>
-__device__ __forceinline__ void lds_row_frag(Frag<T>& f, const T* img, int ldi, int row, int f0, int dhp) {
-    if (f0 < dhp) frag_load(f, img + row * ldi + f0);
-    else frag_zero(f);
+// Feature-contraction step of the long-sequence kernels (S = K Q^T, dP = V dO^T).  fp32: 16 features per step = four 16x16x4 MFMAs with
+// 4 consecutive features per lane -- FCT's heads are 4..64 wide (padded to 8..64), and a 32-wide step would spend eight MFMAs on a
+// head of 8; bf16: the 32-wide single MFMA.
+template <typename T> struct Feat;
+template <> struct Feat<float> { static constexpr int W = 16; typedef Frag16<float> F; };
+template <> struct Feat<bf16> { static constexpr int W = 32; typedef Frag<bf16> F; };
+__device__ __forceinline__ void ff_load(Frag16<float>& f, const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+}
+__device__ __forceinline__ void ff_load(Frag<bf16>& f, const bf16* p) { frag_load(f, p); }
+__device__ __forceinline__ void ff_zero(Frag16<float>& f) { f.v[0] = f.v[1] = f.v[2] = f.v[3] = 0.f; }
+__device__ __forceinline__ void ff_zero(Frag<bf16>& f) { frag_zero(f); }
+__device__ __forceinline__ f32x4 ff_mma(const Frag16<float>& a, const Frag16<float>& b, f32x4 c) { return mma16(a, b, c); }
+__device__ __forceinline__ f32x4 ff_mma(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) { return mma32(a, b, c); }
+template <typename T, typename F>
+__device__ __forceinline__ void ff_row(F& f, const T* row, int f0, int dhp) {      // features f0 .. of one row (global or LDS)
+    if (f0 < dhp) ff_load(f, row + f0);
+    else ff_zero(f);
 }
 
 template <typename T>
@@ -560,16 +575,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    using FF = typename Feat<T>::F;
+    constexpr int FW = Feat<T>::W, FL = FW / 4, MAXFS = 16 * MAXDT / FW;       // step width, features per lane and step, most steps
+    const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int query = blockIdx.x * 64 + wave * 16 + p;
     const int qrow = query < L ? query : L - 1;
-    Frag<T> fq[4];
+    FF fq[MAXFS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (s < ks) {
-            const int f0 = s * 32 + 8 * g;
-            if (f0 < dhp) frag_load(fq[s], q + base + (long long)qrow * ld + f0); else frag_zero(fq[s]);
-        }
+    for (int s = 0; s < MAXFS; ++s)
+        if (s < ks) ff_row<T>(fq[s], q + base + (long long)qrow * ld, s * FW + FL * g, dhp);
     float m = -INFINITY, l = 0.f;
     f32x4 o[MAXDT];
 #pragma unroll
@@ -594,11 +608,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
         for (int kt = 0; kt < 4; ++kt) {
             sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < MAXFS; ++s)
                 if (s < ks) {
-                    Frag<T> a;
-                    lds_row_frag(a, Kimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
-                    sT[kt] = mma32(a, fq[s], sT[kt]);
+                    FF a;
+                    ff_row<T>(a, Kimg + (kt * 16 + p) * ldi, s * FW + FL * g, dhp);
+                    sT[kt] = ff_mma(a, fq[s], sT[kt]);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -670,17 +684,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    using FF = typename Feat<T>::F;
+    constexpr int FW = Feat<T>::W, FL = FW / 4;
+    const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int query = blockIdx.x * 64 + wave * 16 + p;
     const int qrow = query < L ? query : L - 1;
-    constexpr int KSC = (DTC + 1) / 2;
-    Frag<T> fq[KSC], fg[KSC];
+    constexpr int KSC = (DTC * 16 + FW - 1) / FW;
+    FF fq[KSC], fg[KSC];
 #pragma unroll
     for (int s = 0; s < KSC; ++s)
         if (s < ks) {
-            const int f0 = s * 32 + 8 * g;
-            if (f0 < dhp) { frag_load(fq[s], q + base + (long long)qrow * ld + f0); frag_load(fg[s], dout + base + (long long)qrow * ld + f0); }
-            else { frag_zero(fq[s]); frag_zero(fg[s]); }
+            ff_row<T>(fq[s], q + base + (long long)qrow * ld, s * FW + FL * g, dhp);
+            ff_row<T>(fg[s], dout + base + (long long)qrow * ld, s * FW + FL * g, dhp);
         }
     const float lse_q = lse[(long long)blockIdx.y * L + qrow], dl = delta[(long long)blockIdx.y * L + qrow];
     f32x4 acc[DTC];
@@ -706,11 +721,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
 #pragma unroll
             for (int s = 0; s < KSC; ++s)
                 if (s < ks) {
-                    Frag<T> a, b;
-                    lds_row_frag(a, Kimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
-                    lds_row_frag(b, Vimg, ldi, kt * 16 + p, s * 32 + 8 * g, dhp);
-                    sT = mma32(a, fq[s], sT);
-                    dpT = mma32(b, fg[s], dpT);
+                    FF a, b;
+                    ff_row<T>(a, Kimg + (kt * 16 + p) * ldi, s * FW + FL * g, dhp);
+                    ff_row<T>(b, Vimg + (kt * 16 + p) * ldi, s * FW + FL * g, dhp);
+                    sT = ff_mma(a, fq[s], sT);
+                    dpT = ff_mma(b, fg[s], dpT);
                 }
             float x[4];
 #pragma unroll
@@ -756,17 +771,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    const int DT = (dhp + 15) >> 4, ks = (dhp + 31) >> 5, segs = dhp >> 3;
+    using FF = typename Feat<T>::F;
+    constexpr int FW = Feat<T>::W, FL = FW / 4;
+    const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int key = blockIdx.x * 64 + wave * 16 + p;
     const int krow = key < L ? key : L - 1;
-    constexpr int KSC = (DTC + 1) / 2;
-    Frag<T> fk[KSC], fv[KSC];
+    constexpr int KSC = (DTC * 16 + FW - 1) / FW;
+    FF fk[KSC], fv[KSC];
 #pragma unroll
     for (int s = 0; s < KSC; ++s)
         if (s < ks) {
-            const int f0 = s * 32 + 8 * g;
-            if (f0 < dhp) { frag_load(fk[s], k + base + (long long)krow * ld + f0); frag_load(fv[s], v + base + (long long)krow * ld + f0); }
-            else { frag_zero(fk[s]); frag_zero(fv[s]); }
+            ff_row<T>(fk[s], k + base + (long long)krow * ld, s * FW + FL * g, dhp);
+            ff_row<T>(fv[s], v + base + (long long)krow * ld, s * FW + FL * g, dhp);
         }
     f32x4 dkT[DTC], dvT[DTC];
 #pragma unroll
@@ -795,11 +811,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
 #pragma unroll
             for (int s = 0; s < KSC; ++s)
                 if (s < ks) {
-                    Frag<T> a, b;
-                    lds_row_frag(a, Qimg, ldi, qt * 16 + p, s * 32 + 8 * g, dhp);
-                    lds_row_frag(b, Gimg, ldi, qt * 16 + p, s * 32 + 8 * g, dhp);
-                    sN = mma32(a, fk[s], sN);
-                    dpN = mma32(b, fv[s], dpN);
+                    FF a, b;
+                    ff_row<T>(a, Qimg + (qt * 16 + p) * ldi, s * FW + FL * g, dhp);
+                    ff_row<T>(b, Gimg + (qt * 16 + p) * ldi, s * FW + FL * g, dhp);
+                    sN = ff_mma(a, fk[s], sN);
+                    dpN = ff_mma(b, fv[s], dpN);
                 }
             float ds[4], pv[4];
 #pragma unroll
