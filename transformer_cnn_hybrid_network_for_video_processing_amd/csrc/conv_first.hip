@@ -21,7 +21,8 @@ constexpr int S1_NPIX = S1_TH * S1_TW;         // 256 pixels per tile
 constexpr int S1_PS = S1_KP + 8;               // P row stride (elements); S1_KP (padded K) is in conv_first.h
 constexpr int S1_MAXPART = 2048;               // most workgroups (= partial statistics rows) of the statistics pass (workspace size)
 constexpr int S1_FWD_WGS = 1024;               // its default grid: four workgroups per CU (512 measured 40% slower)
-constexpr int S1_BWD_PART = 512;               // workgroups (= partial rows) of the one-pass backward
+constexpr int S1_BWD_PART = 1024;              // most workgroups (= partial rows) of the one-pass backward and of the Gram pass (workspace size)
+constexpr int S1_BWD_WGS = 512;                // default grid of the block-level backward (two workgroups per CU)
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_s1;
 
@@ -386,7 +387,8 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
 // n*mean(dz)*mean(P)), so the workgroup partial rows are summed in DOUBLE and the tiny-matrix algebra below runs in double:
 // 36*Co threads, free.  (The fp32 partial rows themselves carry ~1e-6 relative error each, uncorrelated across the 512 of them.)
 template <typename T>
-__global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __restrict__ red, const T* __restrict__ wp, const float* __restrict__ mi,
+__global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __restrict__ red, const double* __restrict__ G, const T* __restrict__ wp,
+                                                              const float* __restrict__ mi,
                                                               const float* __restrict__ gamma, int training, double inv_count, int Co, int Ci,
                                                               int Cop, float* __restrict__ dw, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
@@ -394,7 +396,6 @@ __global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __re
     if (i >= Co * 36) return;
     const int co = i / 36, k = i - co * 36;
     const double* S1 = red + (long long)co * 48;
-    const double* G = red + (long long)Cop * 48;
     auto g_at = [&](int r, int c) { return (r / 16 <= c / 16) ? G[r * 48 + c] : G[c * 48 + r]; };      // symmetric
     const double mean = mi[co], inv = mi[Cop + co];
     const double sdz = S1[36];
@@ -414,6 +415,53 @@ __global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __re
         if (dbeta) dbeta[co] = (float)sdz;
         if (dgamma) dgamma[co] = (float)sdzx;
     }
+}
+
+// BatchNorm batch statistics of stage 1 from the Gram matrix of the patches (stage1w_gram_kernel): one thread per channel, in double.
+//   sum y = w . G[:,36],  sum y^2 = w^T G w   (w = the storage-rounded weights the conv kernels multiply with)
+// followed by what bn_stats_finalize_kernel does (UNet.py:59 semantics: biased variance for the normalisation, unbiased for the running
+// estimate, momentum update, num_batches_tracked).
+template <typename T>
+__global__ __launch_bounds__(64) void s1_gram_stats_kernel(const double* __restrict__ G, const T* __restrict__ wp, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                           long long* __restrict__ nbt, float momentum, float eps, long long count, int Co, int Cop,
+                                                           float* __restrict__ scale_shift, float* __restrict__ mean_invstd, float* running_out) {
+    // one wave per channel: lane k < 36 forms row k of G w (36 independent loads), the two sums are fixed-order wave reductions
+    __shared__ double wl[36];
+    const int c = blockIdx.x, k = threadIdx.x;
+    if (c == 0 && k == 0 && nbt && !running_out) *nbt += 1;
+    auto g_at = [&](int r, int cc) { return (r / 16 <= cc / 16) ? G[r * 48 + cc] : G[cc * 48 + r]; };
+    if (k < 36) wl[k] = c < Co ? (double)to_f32<T>(wp[(long long)c * 64 + k]) : 0.0;
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    if (k < 36 && c < Co) {
+        double row = 0.0;
+#pragma unroll 6
+        for (int kk = 0; kk < 36; ++kk) row = fma(wl[kk], g_at(k, kk), row);
+        s2 = wl[k] * row;
+        s1 = wl[k] * g_at(k, 36);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (k != 0) return;
+    float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
+    if (c < Co) {
+        const double inv_n = 1.0 / (double)count;
+        const double m = s1 * inv_n;
+        double var = s2 * inv_n - m * m;
+        if (var < 0.0) var = 0.0;
+        g = gamma[c]; b = beta[c];
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float unbiased = (float)(count > 1 ? var * ((double)count / (double)(count - 1)) : var);
+        (running_out ? running_out : running_mean)[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        (running_out ? running_out + Co : running_var)[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    const float scale = g * invstd;
+    scale_shift[c] = scale;
+    scale_shift[Cop + c] = b - mean * scale;
+    mean_invstd[c] = mean;
+    mean_invstd[Cop + c] = invstd;
 }
 
 // fixed-order DOUBLE sum of the MODE 4 partial rows: column i = sum_g part[g*n + i]; 256 threads = 32 columns x 8 row groups
@@ -488,7 +536,9 @@ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // ---- internal entry points used by hyb_convstage_{fwd,bwd} when first = 1 ----------------------------------------------
 size_t hyb_stage1_fwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
-    return 2 * al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256((size_t)S1_MAXPART * 2 * Cop * 4);
+    size_t part = (size_t)S1_MAXPART * 2 * Cop * 4;
+    if (part < (size_t)S1_BWD_PART * 2304 * 4) part = (size_t)S1_BWD_PART * 2304 * 4;            // Gram partial rows (statistics from G)
+    return 2 * al256((size_t)Cop * 64 * es) + al256(2 * (size_t)Cop * 4) + al256(part) + al256((size_t)S1_GRAM_DOUBLES * 8);
 }
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -514,13 +564,23 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     T* wp2 = packed_out ? (T*)packed_out + (size_t)Cop * 64 : (T*)ws;   ws += al256((size_t)Cop * 64 * es);
     float* stats = (float*)ws;                   ws += al256(2 * (size_t)Cop * 4);
     float* part = (float*)ws;
+    {
+        size_t pb = (size_t)S1_MAXPART * 2 * Cop * 4;
+        if (pb < (size_t)S1_BWD_PART * 2304 * 4) pb = (size_t)S1_BWD_PART * 2304 * 4;
+        ws += al256(pb);
+    }
+    // Gram matrix (double): kept for backward behind the packed weights when asked, else scratch
+    double* gram = packed_out ? (double*)((T*)packed_out + (size_t)Cop * 128) : (double*)ws;
     const long long total = (long long)Cop * 64;
     static const int wave_env = getenv("HYB_S1_WAVE") ? atoi(getenv("HYB_S1_WAVE")) : 1;          // second-generation forward passes (A/B)
     // they address x and pooled with 32-bit buffer offsets and load aligned float4 row segments
     const bool vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const bool wave_private = wave_env && vec_ok && (long long)N * Ci * H * W * 4 < (1ll << 32) &&
                               (long long)N * (H / 2) * (W / 2) * Cop * (long long)es < (1ll << 32);
-    if (packed_out || !wave_private) {                       // k = tap*4 + c: the block-level kernels and the backward pass
+    // statistics from the Gram matrix: 16-bit storage, training mode, no ragged 8x16 blocks (same test as the backward's wave-private kernel)
+    static const int gram_env = getenv("HYB_S1_GRAM") ? atoi(getenv("HYB_S1_GRAM")) : 1;
+    const bool use_gram = gram_env && wave_private && training && sizeof(T) == 2 && (W % 16 == 0) && (H % 8 == 0);
+    if (packed_out || !wave_private || use_gram) {           // k = tap*4 + c: the block-level kernels, the Gram statistics and the backward pass
         hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
         HYB_LAUNCH_CHECK();
     }
@@ -538,7 +598,25 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     const int gx = s1_grid(numTiles);
     int rc;
     int gx_rows = gx;                                      // partial statistics rows actually written
-    if (training) {
+    if (packed_out) {
+        // defined contents for the whole saved buffer (its size is counted in 2-byte elements: twice the need with fp32 storage): the
+        // Gram slot's padding always, the slot itself when this path does not produce it
+        const size_t tail = (size_t)S1_GRAM_DOUBLES * 4 * es, used = (size_t)2304 * 8;
+        const bool produced = training && use_gram;
+        if (hipError_t e = hipMemsetAsync((char*)gram + (produced ? used : 0), 0, tail - (produced ? used : 0), st)) return (int)e;
+    }
+    if (training && use_gram) {
+        static const int gram_wgs = getenv("HYB_S1_GRAM_WGS") ? atoi(getenv("HYB_S1_GRAM_WGS")) : 512;          // 1024 measured 0.5 % slower
+        int grows = gram_wgs < 1 ? 1 : (gram_wgs > S1_BWD_PART ? S1_BWD_PART : gram_wgs);
+        rc = hyb_stage1w_gram(dtype, a, grows, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(2304, 32)), dim3(256), 0, st, part, gram, grows, 2304ll);
+        HYB_LAUNCH_CHECK();
+        hipLaunchKernelGGL(s1_gram_stats_kernel<T>, dim3(Cop), dim3(64), 0, st, (const double*)gram, (const T*)wp, gamma, beta, running_mean,
+                           running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop, scale_shift, mean_invstd, running_out);
+        HYB_LAUNCH_CHECK();
+        rc = 0;
+    } else if (training) {
         rc = wave_private ? hyb_stage1w_pass(dtype, 0, a, gx_rows, st) : s1_dispatch<T, 0>(a, gx, st);
         if (rc) return rc;
         rc = hyb_bn_stats_finalize(part, gx_rows, gamma, beta, running_mean, running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop,
@@ -590,15 +668,23 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
     // one pass over x and dpooled (MODE 4), a fixed-order sum of the partial rows, and a finalize on tiny matrices
-    static const int bwd_wgs = getenv("HYB_S1_BWD_WGS") ? atoi(getenv("HYB_S1_BWD_WGS")) : S1_BWD_PART;      // <= S1_BWD_PART (workspace)
-    int gx = (int)(numTiles < bwd_wgs ? numTiles : bwd_wgs);
+    static const int bwd_wgs = getenv("HYB_S1_BWD_WGS") ? atoi(getenv("HYB_S1_BWD_WGS")) : 0;                // 0: 512 (768 = three workgroups per CU for the kernel without G measured 1 % slower)
+    // (saved_g is decided below from the same inputs; the grid only needs the bound)
+    int want = bwd_wgs > 0 ? bwd_wgs : S1_BWD_WGS;
+    if (want > S1_BWD_PART) want = S1_BWD_PART;
+    int gx = (int)(numTiles < want ? numTiles : want);
     if (gx < 1) gx = 1;
     const long long roww = (long long)Cop * 48 + 2304;
-    int rc = wave_private ? hyb_stage1w_bwd(dtype, a, gx, st) : s1_dispatch<T, 4>(a, gx, st);
+    // the forward pass of a training step (same conditions) left the Gram matrix behind the packed weights: accumulate S1 only
+    static const int gram_env = getenv("HYB_S1_GRAM") ? atoi(getenv("HYB_S1_GRAM")) : 1;
+    const bool saved_g = gram_env && wave_private && training && packed_in != nullptr;
+    const long long rw = saved_g ? (long long)Cop * 48 : roww;
+    int rc = wave_private ? hyb_stage1w_bwd(dtype, a, saved_g ? 0 : 1, gx, st) : s1_dispatch<T, 4>(a, gx, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(roww, 32)), dim3(256), 0, st, part, sums, gx, roww);
+    hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(rw, 32)), dim3(256), 0, st, part, sums, gx, rw);
     HYB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(s1_bwd_finalize_kernel<T>, dim3(hyb_cdiv(Co * 36, 256)), dim3(256), 0, st, sums, wp, mean_invstd, gamma, training,
+    const double* Gp = saved_g ? (const double*)((const T*)packed_in + (size_t)Cop * 128) : sums + (size_t)Cop * 48;
+    hipLaunchKernelGGL(s1_bwd_finalize_kernel<T>, dim3(hyb_cdiv(Co * 36, 256)), dim3(256), 0, st, sums, Gp, wp, mean_invstd, gamma, training,
                        1.0 / (double)((long long)N * H * W), Co, Ci, Cop, dweight, dgamma, dbeta);
     HYB_LAUNCH_CHECK();
     return 0;

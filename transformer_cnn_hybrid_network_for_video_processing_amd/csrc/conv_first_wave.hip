@@ -279,15 +279,16 @@ template <> struct S1BTr<bf16> {
     }
 };
 
-template <typename T, int NT, int CI>
+template <typename T, int NT, int CI, bool WITH_G /* false: the forward pass saved G (stage1w_gram_kernel), only S1 is accumulated */>
 __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int DS = NT * 16 + 8;                                            // dz row stride (elements): odd multiple of 16 bytes
-    constexpr int WAVE_EL = 2 * S1W_IMG + 64 * DS + S1B_CT;
+    constexpr int WAVE_EL = S1W_IMG + 64 * DS + S1B_CT;                        // ONE image: a wave's LDS operations execute in order, so the next
+                                                                               // block's image can be written once this block's reads are issued
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     T* img0 = reinterpret_cast<T*>(smem_raw) + wave * WAVE_EL;
-    T* dyt = img0 + 2 * S1W_IMG;                                               // [64 pixels][DS]
+    T* dyt = img0 + S1W_IMG;                                                   // [64 pixels][DS]
     T* ctab = dyt + 64 * DS;
     const int p = lane & 15, q = lane >> 4, wy = p >> 2, wx = p & 3;
     const int pp = lane & 3, qq = (lane & 15) >> 2;
@@ -393,11 +394,10 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
             }
         }
     };
-    int cur = 0;
     if (nblk > 0) { prefetch(n_c, by_c, bx_c); stage(img0); advance(n_n, by_n_, bx_n_); }
 
     for (int it = 0; it < nblk; ++it) {
-        const T* img = img0 + cur * S1W_IMG;
+        const T* img = img0;
         const bool more = it + 1 < nblk;
         Vec8<T> gcur[2][NT / 2];
 #pragma unroll
@@ -481,18 +481,18 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
 #pragma unroll
                     for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf[kt], wacc[kt][c]);
                 }
-                if (blockIdx.y == 0) {
+                if (WITH_G && blockIdx.y == 0) {
                     gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
                     gacc[3] = mma32(bf[1], bf[1], gacc[3]); gacc[4] = mma32(bf[1], bf[2], gacc[4]); gacc[5] = mma32(bf[2], bf[2], gacc[5]);
                 }
             }
         }
-        if (more) { stage(img0 + (cur ^ 1) * S1W_IMG); advance(n_n, by_n_, bx_n_); }
+        if (more) { stage(img0); advance(n_n, by_n_, bx_n_); }
         advance(n_c, by_c, bx_c);
-        cur ^= 1;
     }
 
     // combine the 4 waves through LDS: row = [S1: Cop x 48][G: 48 x 48 (upper triangle tiles filled)] -- the block-level kernel's layout
+    // (without G the rows are Cop x 48 long)
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem_raw);                           // [4][NT*16*48 + 2304]
     constexpr int RW = NT * 16 * 48 + 2304;
@@ -508,11 +508,11 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     };
     put_g(0, 0, 0); put_g(1, 0, 1); put_g(2, 0, 2); put_g(3, 1, 1); put_g(4, 1, 2); put_g(5, 2, 2);
     __syncthreads();
-    const long long roww = (long long)Cop * 48 + 2304;
+    const long long roww = (long long)Cop * 48 + (WITH_G ? 2304 : 0);
     float* out = a.part + (long long)blockIdx.x * roww;
     for (int i = tid; i < NT * 16 * 48; i += 256)
         out[(long long)co_base * 48 + i] = (red[i] + red[RW + i]) + (red[2 * RW + i] + red[3 * RW + i]);
-    if (blockIdx.y == 0) {
+    if (WITH_G && blockIdx.y == 0) {
         for (int i = tid; i < 2304; i += 256) {
             const int gr = i / 48, gc = i % 48;
             const int o = NT * 16 * 48 + i;
@@ -521,20 +521,126 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     }
 }
 
-template <typename T, int NT>
+// ---- Gram pass: G = P^T P over all pixels (48 x 48, upper-triangle tiles), the im2col patches read as in the backward kernel.
+// G depends on the frames only.  It serves the BatchNorm batch statistics (column 36 of P is all ones: G[k][36] = sum P[k], and
+//   sum_pix y_co = w_co . G[:,36],   sum_pix y_co^2 = w_co^T G w_co      -- no conv, no per-pixel squares: 12 MFMAs and no vector
+// epilogue per 64 pixels instead of 16 MFMAs + 64 packed adds/fmas) and is kept for the backward pass, which then accumulates S1 only.
+template <typename T, int CI>
+__global__ __launch_bounds__(256) void stage1w_gram_kernel(S1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int WAVE_EL = S1W_IMG + S1B_CT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T* img = reinterpret_cast<T*>(smem_raw) + wave * WAVE_EL;                  // one image: the next block's rows wait in registers
+    T* ctab = img + S1W_IMG;
+    const int q = lane >> 4, p = lane & 15, pp = lane & 3, qq = (lane & 15) >> 2;
+    const int H = a.H, W = a.W, Ci = a.Ci;
+    if (lane < S1B_CT) ctab[lane] = from_f32<T>(lane == 0 ? 1.f : 0.f);
+    f32x4 gacc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bx_n = a.tilesX, by_n = a.tilesY, bpi = bx_n * by_n;
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    const int chunk = (a.numTiles + nwaves - 1) / nwaves;
+    const int blk_begin = gw * chunk < a.numTiles ? gw * chunk : a.numTiles;
+    const int blk_end = blk_begin + chunk < a.numTiles ? blk_begin + chunk : a.numTiles;
+    const int nblk = blk_end - blk_begin;
+    const int hrow = lane / 6, hseg = lane - hrow * 6;
+    const bool hlane = lane < 60;
+    const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);
+    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);
+    const unsigned plane = (unsigned)(H * W) * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
+    const unsigned OOB = 0xFFFFFFF0u;
+    const int pix_lo = ((q >> 1) * S1W_R + 4 * (q & 1) + qq + 3) * 4;
+    int boff[3];
+    bool bconst[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tap = 4 * kt + pp;
+        bconst[kt] = tap >= 9;
+        boff[kt] = tap < 9 ? pix_lo + ((tap / 3) * S1W_R + tap % 3) * 4 : (tap - 9) * 4;
+    }
+    int n_c = blk_begin / bpi, by_c, bx_c;
+    { const int rem = blk_begin - n_c * bpi; by_c = rem / bx_n; bx_c = rem - by_c * bx_n; }
+    n_c = __builtin_amdgcn_readfirstlane(n_c); by_c = __builtin_amdgcn_readfirstlane(by_c); bx_c = __builtin_amdgcn_readfirstlane(bx_c);
+    auto advance = [&](int& n, int& by, int& bx) {
+        ++bx;
+        if (bx == bx_n) { bx = 0; ++by; if (by == by_n) { by = 0; ++n; } }
+    };
+    f32x4 pf[4];
+    auto prefetch = [&](int n, int by, int bx) {
+        const int row0 = by * 8 - 1, col0 = bx * S1W_BW - 4;
+        const unsigned bo = (unsigned)((((long long)n * Ci * H + row0) * W + col0) * 4);
+        const bool ok = hlane && (unsigned)(row0 + hrow) < (unsigned)H && (unsigned)(col0 + 4 * hseg) <= (unsigned)(W - 4);
+        const unsigned voff = ok ? ld_lane + bo : OOB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (CI ? c < CI : c < Ci) pf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * plane, 0));
+            else pf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {
+        if (hlane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Quad<T> qv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                *reinterpret_cast<Quad<T>*>(img + st_lds + i * 4) = qv;
+            }
+        }
+    };
+    if (nblk > 0) { prefetch(n_c, by_c, bx_c); stage(); advance(n_c, by_c, bx_c); }
+    for (int it = 0; it < nblk; ++it) {
+        const bool more = it + 1 < nblk;
+        if (more) prefetch(n_c, by_c, bx_c);                          // in flight under this block's work
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> bf[3];
+                const int pstep = (4 * ks * S1W_R + 8 * sb) * 4;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const T* lo = bconst[kt] ? ctab + boff[kt] : img + boff[kt] + pstep;
+                    const T* hi = bconst[kt] ? lo : lo + 2 * S1W_R * 4;
+                    S1BTr<T>::read(bf[kt], lo, hi);
+                }
+                gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
+                gacc[3] = mma32(bf[1], bf[1], gacc[3]); gacc[4] = mma32(bf[1], bf[2], gacc[4]); gacc[5] = mma32(bf[2], bf[2], gacc[5]);
+            }
+        if (more) { stage(); advance(n_c, by_c, bx_c); }              // same buffer: this wave's reads of it are all issued (in-order LDS)
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);                           // [4][2304]
+    auto put_g = [&](int i, int gi, int gj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 2304 + (gi * 16 + 4 * q + r) * 48 + gj * 16 + p] = gacc[i][r];
+    };
+    put_g(0, 0, 0); put_g(1, 0, 1); put_g(2, 0, 2); put_g(3, 1, 1); put_g(4, 1, 2); put_g(5, 2, 2);
+    __syncthreads();
+    float* out = a.part + (long long)blockIdx.x * 2304;
+    for (int i = tid; i < 2304; i += 256) {
+        const int gr = i / 48, gc = i % 48;
+        out[i] = (gr / 16 <= gc / 16) ? (red[i] + red[2304 + i]) + (red[2 * 2304 + i] + red[3 * 2304 + i]) : 0.f;
+    }
+}
+
+template <typename T, int NT, bool WITH_G>
 int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
     constexpr int DS = NT * 16 + 8;
-    size_t lds = (size_t)4 * (2 * S1W_IMG + 64 * DS + S1B_CT) * sizeof(T);
+    size_t lds = (size_t)4 * (S1W_IMG + 64 * DS + S1B_CT) * sizeof(T);
     const size_t red = (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
     if (red > lds) lds = red;
     lds += 64;
     dim3 grid(grid_x, a.Cop / (NT * 16));
     if (lds > 64 * 1024) {
         static HybAttrOnce once3, once0;
-        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_kernel<T, NT, 3> : (const void*)stage1w_bwd_kernel<T, NT, 0>, (int)lds)) return e;
+        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_kernel<T, NT, 3, WITH_G> : (const void*)stage1w_bwd_kernel<T, NT, 0, WITH_G>, (int)lds)) return e;
     }
-    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 3>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 0>), grid, dim3(256), lds, st, a);
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 3, WITH_G>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 0, WITH_G>), grid, dim3(256), lds, st, a);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -589,15 +695,32 @@ int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, 
 
 // backward pass over 8x16 blocks; `a` as for the block-level MODE 4 launch (wp2 set); bf16 only (the transposing LDS read is a 16-bit
 // instruction): fp32 parity mode keeps the block-level kernel
-int hyb_stage1w_bwd(int dtype, S1Args a, int& grid_x, hipStream_t st) {
+int hyb_stage1w_bwd(int dtype, S1Args a, int with_g, int& grid_x, hipStream_t st) {
     if (dtype != HYB_BF16) return HYB_E_ARG;
     a.tilesX = hyb_cdiv(a.W, S1W_BW); a.tilesY = hyb_cdiv(a.H, 8);
     const long long nb = (long long)a.N * a.tilesX * a.tilesY;
     if (nb >= (1ll << 30)) return HYB_E_ARG;
     a.numTiles = (int)nb;
     if ((long long)grid_x * 4 > nb) grid_x = (int)((nb + 3) / 4);
-    if (a.Cop % 64 == 0) return s1w_bwd_launch<bf16, 4>(a, grid_x, st);
-    return s1w_bwd_launch<bf16, 2>(a, grid_x, st);
+    if (a.Cop % 64 == 0) return with_g ? s1w_bwd_launch<bf16, 4, true>(a, grid_x, st) : s1w_bwd_launch<bf16, 4, false>(a, grid_x, st);
+    return with_g ? s1w_bwd_launch<bf16, 2, true>(a, grid_x, st) : s1w_bwd_launch<bf16, 2, false>(a, grid_x, st);
+}
+
+// Gram pass over 8x16 blocks (no ragged blocks: H % 8 == 0, W % 16 == 0); writes grid_x partial rows of 2304 floats to a.part
+int hyb_stage1w_gram(int dtype, S1Args a, int& grid_x, hipStream_t st) {
+    if (dtype != HYB_BF16) return HYB_E_ARG;
+    a.tilesX = hyb_cdiv(a.W, S1W_BW); a.tilesY = hyb_cdiv(a.H, 8);
+    const long long nb = (long long)a.N * a.tilesX * a.tilesY;
+    if (nb >= (1ll << 30)) return HYB_E_ARG;
+    a.numTiles = (int)nb;
+    if ((long long)grid_x * 4 > nb) grid_x = (int)((nb + 3) / 4);
+    size_t lds = (size_t)4 * (S1W_IMG + S1B_CT) * sizeof(bf16);
+    if (lds < (size_t)4 * 2304 * sizeof(float)) lds = (size_t)4 * 2304 * sizeof(float);
+    lds += 64;
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_gram_kernel<bf16, 3>), dim3(grid_x), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_gram_kernel<bf16, 0>), dim3(grid_x), dim3(256), lds, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
 }
 
 int hyb_stage1w_pass(int dtype, int mode, const S1Args& a, int& grid_x, hipStream_t st) {

@@ -87,8 +87,9 @@ inline unsigned long long drop_seed(unsigned long long seed, int layer) { return
 // ----------------------------------------------------------------------------------------------------------
 // conv stage
 // ----------------------------------------------------------------------------------------------------------
-// first stage: the packed weights in both K orders of conv_first.hip / conv_first_wave.hip, [2][Cop][64]
-extern "C" long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop) { return first ? (long long)Cop * 128 : (long long)Cip * 9 * Cop; }
+// first stage: the packed weights in both K orders of conv_first.hip / conv_first_wave.hip, [2][Cop][64], followed by the Gram matrix of
+// the patches in double (2306 x 8 bytes, counted here in 2-byte elements so that the buffer is large enough for either dtype)
+extern "C" long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop) { return first ? (long long)Cop * 128 + 2306 * 4 : (long long)Cip * 9 * Cop; }
 
 extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop) {
     if (first) return hyb_stage1_fwd_workspace(dtype, Cop);
