@@ -28,7 +28,7 @@ struct S1Args {
 };
 
 // conv_first_wave.hip
-int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, hipStream_t st);
+int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, int both, hipStream_t st);
 int hyb_stage1w_bwd(int dtype, S1Args a, int with_g /* 0: rows are Cop x 48 (G saved by the forward pass) */, int& grid_x /* in: wanted workgroups; out: launched = partial rows */, hipStream_t st);
 int hyb_stage1w_gram(int dtype, S1Args a, int& grid_x, hipStream_t st);
 constexpr int S1_GRAM_DOUBLES = 2304 + 2;          // saved Gram matrix (48 x 48, upper-triangle tiles) + pad, after the two packed weight layouts

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void s1_bwd_finalize_kernel(const double* __re
 // followed by what bn_stats_finalize_kernel does (UNet.py:59 semantics: biased variance for the normalisation, unbiased for the running
 // estimate, momentum update, num_batches_tracked).
 template <typename T>
-__global__ __launch_bounds__(64) void s1_gram_stats_kernel(const double* __restrict__ G, const T* __restrict__ wp, const float* __restrict__ gamma,
+__global__ __launch_bounds__(64) void s1_gram_stats_kernel(double* __restrict__ G /* [2304] read, [2304..2305] padding zeroed */, const T* __restrict__ wp, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* running_mean, float* running_var,
                                                            long long* __restrict__ nbt, float momentum, float eps, long long count, int Co, int Cop,
                                                            float* __restrict__ scale_shift, float* __restrict__ mean_invstd, float* running_out) {
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(64) void s1_gram_stats_kernel(const double* __restr
     __shared__ double wl[36];
     const int c = blockIdx.x, k = threadIdx.x;
     if (c == 0 && k == 0 && nbt && !running_out) *nbt += 1;
+    if (c == 0 && k < S1_GRAM_DOUBLES - 2304) G[2304 + k] = 0.0;
     auto g_at = [&](int r, int cc) { return (r / 16 <= cc / 16) ? G[r * 48 + cc] : G[cc * 48 + r]; };
     if (k < 36) wl[k] = c < Co ? (double)to_f32<T>(wp[(long long)c * 64 + k]) : 0.0;
     __syncthreads();
@@ -580,12 +581,16 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     // statistics from the Gram matrix: 16-bit storage, training mode, no ragged 8x16 blocks (same test as the backward's wave-private kernel)
     static const int gram_env = getenv("HYB_S1_GRAM") ? atoi(getenv("HYB_S1_GRAM")) : 1;
     const bool use_gram = gram_env && wave_private && training && sizeof(T) == 2 && (W % 16 == 0) && (H % 8 == 0);
-    if (packed_out || !wave_private || use_gram) {           // k = tap*4 + c: the block-level kernels, the Gram statistics and the backward pass
-        hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
-        HYB_LAUNCH_CHECK();
-    }
-    if (wave_private || packed_out) {
-        if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, st)) return e;
+    const bool need_a = packed_out || !wave_private || use_gram;     // k = tap*4 + c: the block-level kernels, the Gram statistics, the backward pass
+    const bool need_b = wave_private || packed_out;
+    if (need_a && need_b && wp2 == wp + (size_t)Cop * 64) {          // the two layouts are adjacent (always: Cop*64*es is a multiple of 256): one launch
+        if (int e = hyb_stage1w_pack(dtype, weight, wp, Co, Ci, Cop, 1, st)) return e;
+    } else {
+        if (need_a) {
+            hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
+            HYB_LAUNCH_CHECK();
+        }
+        if (need_b) { if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, 0, st)) return e; }
     }
     S1Args a{};
     a.x = x; a.wp = wp; a.wp2 = wp2; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.pooled = pooled; a.part = part;
@@ -601,9 +606,9 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     if (packed_out) {
         // defined contents for the whole saved buffer (its size is counted in 2-byte elements: twice the need with fp32 storage): the
         // Gram slot's padding always, the slot itself when this path does not produce it
-        const size_t tail = (size_t)S1_GRAM_DOUBLES * 4 * es, used = (size_t)2304 * 8;
-        const bool produced = training && use_gram;
-        if (hipError_t e = hipMemsetAsync((char*)gram + (produced ? used : 0), 0, tail - (produced ? used : 0), st)) return (int)e;
+        // (when it is produced -- 16-bit storage -- the statistics kernel below zeroes the 16 bytes of padding itself: no extra launch)
+        const size_t tail = (size_t)S1_GRAM_DOUBLES * 4 * es;
+        if (!(training && use_gram)) { if (hipError_t e = hipMemsetAsync(gram, 0, tail, st)) return (int)e; }
     }
     if (training && use_gram) {
         static const int gram_wgs = getenv("HYB_S1_GRAM_WGS") ? atoi(getenv("HYB_S1_GRAM_WGS")) : 512;          // 1024 measured 0.5 % slower
@@ -612,7 +617,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
         if (rc) return rc;
         hipLaunchKernelGGL(s1_rows_sum_kernel, dim3(hyb_cdiv(2304, 32)), dim3(256), 0, st, part, gram, grows, 2304ll);
         HYB_LAUNCH_CHECK();
-        hipLaunchKernelGGL(s1_gram_stats_kernel<T>, dim3(Cop), dim3(64), 0, st, (const double*)gram, (const T*)wp, gamma, beta, running_mean,
+        hipLaunchKernelGGL(s1_gram_stats_kernel<T>, dim3(Cop), dim3(64), 0, st, gram, (const T*)wp, gamma, beta, running_mean,
                            running_var, nbt, momentum, eps, (long long)N * H * W, Co, Cop, scale_shift, mean_invstd, running_out);
         HYB_LAUNCH_CHECK();
         rc = 0;
@@ -656,7 +661,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
         const long long total = (long long)Cop * 64;
         hipLaunchKernelGGL(s1_pack_kernel<T>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, wp, Co, Ci, total);
         HYB_LAUNCH_CHECK();
-        if (wave_private) { if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, st)) return e; }
+        if (wave_private) { if (int e = hyb_stage1w_pack(dtype, weight, wp2, Co, Ci, Cop, 0, st)) return e; }
     }
     S1Args a{};
     a.x = x; a.wp = wp; a.wp2 = wp2; a.ss = scale_shift; a.mi = mean_invstd; a.gamma = gamma; a.sums = nullptr; a.dp = dpooled; a.part = part;

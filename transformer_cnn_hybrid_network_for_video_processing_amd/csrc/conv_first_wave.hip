@@ -648,17 +648,21 @@ int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
 // packed first-layer weights for the wave-private forward kernels: T [Cop][64], k = slot*4 + c with the slot -> tap map below
 // (slot pairs (2q, 2q+1) of a k-step are horizontally adjacent pixels; -1 = zero weights)
 template <typename T>
-__global__ void s1w_pack_kernel(const float* __restrict__ w, T* __restrict__ wp2, int Co, int Ci, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__global__ void s1w_pack_kernel(const float* __restrict__ w, T* __restrict__ wp2, int Co, int Ci, long long total, int both) {
+    // `both`: wp2 = [2][Cop][64], the first half in the block-level kernels' order (k = tap*4 + c), the second in this file's order
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (both ? 2 * total : total)) return;
+    const bool second = !both || i >= total;
+    T* dst = wp2 + i;
+    if (both && second) i -= total;
     const int k = (int)(i % 64), co = (int)(i / 64);
     const int slot = k >> 2, c = k & 3;
     //                  k-step 0: (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (0,2)  -    k-step 1: (1,2) -  (2,2) -   -   -   -   -
     const int tap_of_slot[16] = {0, 1, 3, 4, 6, 7, 2, -1, 5, -1, 8, -1, -1, -1, -1, -1};
-    const int tap = tap_of_slot[slot];
+    const int tap = second ? tap_of_slot[slot] : (slot < 9 ? slot : -1);
     float v = 0.f;
     if (co < Co && tap >= 0 && c < Ci) v = w[((long long)co * Ci + c) * 9 + tap];
-    wp2[i] = from_f32<T>(v);
+    *dst = from_f32<T>(v);
 }
 
 template <typename T, int NT, int MODE>
@@ -684,10 +688,11 @@ int s1w_dispatch(S1Args a, int& grid_x /* in: wanted workgroups; out: launched (
 
 }  // namespace
 
-int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, hipStream_t st) {
-    const long long total = (long long)Cop * 64;
-    if (dtype == HYB_F32) hipLaunchKernelGGL(s1w_pack_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, (float*)wp2, Co, Ci, total);
-    else if (dtype == HYB_BF16) hipLaunchKernelGGL(s1w_pack_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, weight, (bf16*)wp2, Co, Ci, total);
+// both = 0: wp2 [Cop][64] in this file's K order; both = 1: wp2 is [2][Cop][64], block-level order first (one launch for the two layouts)
+int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, int both, hipStream_t st) {
+    const long long total = (long long)Cop * 64, n = both ? 2 * total : total;
+    if (dtype == HYB_F32) hipLaunchKernelGGL(s1w_pack_kernel<float>, dim3(hyb_cdiv(n, 256)), dim3(256), 0, st, weight, (float*)wp2, Co, Ci, total, both);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(s1w_pack_kernel<bf16>, dim3(hyb_cdiv(n, 256)), dim3(256), 0, st, weight, (bf16*)wp2, Co, Ci, total, both);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
