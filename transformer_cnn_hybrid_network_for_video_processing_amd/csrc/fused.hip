@@ -6,6 +6,8 @@
 //                            (TransformerEncoder.pyc src L110-126) -> mean over T + Linear head (composite's own)
 #include "hyb_common.h"
 
+size_t hyb_encoder_xin_offset(int dtype, int B, int S, int D, int Hid, int H);
+
 namespace {
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
@@ -107,8 +109,11 @@ extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, 
     HYB_CHECK_ARG(h && token_w && enc_params && head_w && feat && tok && enc_saved && enc_out && logits && B > 0 && S > 0 && HW > 0);
     const int N = B * S;
     HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
-    HYB_TRY(hyb_linear_fwd(dtype, feat, Cp, token_w, token_b, tok, N, D, C, 0, stream));
-    HYB_TRY(hyb_encoder_fwd(dtype, tok, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream));
+    // the tokens are written straight into the encoder's saved input slot (`tok` stays an unused scratch argument of the ABI)
+    void* tok_dst = (char*)enc_saved + hyb_encoder_xin_offset(dtype, B, S, D, Hid, H);
+    (void)tok;
+    HYB_TRY(hyb_linear_fwd(dtype, feat, Cp, token_w, token_b, tok_dst, N, D, C, 0, stream));
+    HYB_TRY(hyb_encoder_fwd(dtype, tok_dst, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream));
     HYB_TRY(hyb_head_fwd(dtype, enc_out, head_w, head_b, logits, B, S, D, classes, stream));
     return 0;
 }

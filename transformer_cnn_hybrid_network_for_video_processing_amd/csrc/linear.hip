@@ -310,11 +310,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
 
 // fp32 master weight W[N][K] -> T copy Wc[N][K] and T transpose Wt[K][N] (one 32x32 tile per block, grouped over blockIdx.z)
 struct ConvertArgs {
-    const float* W[8];
-    void* Wc[8];
-    void* Wt[8];
-    int N[8], K[8];
-    int ldt[8];             // row stride of the transposed copy (>= N; lets several transposes share one [K][sum N] buffer)
+    const float* W[18];
+    void* Wc[18];
+    void* Wt[18];
+    int N[18], K[18];
+    int ldt[18];             // row stride of the transposed copy (>= N; lets several transposes share one [K][sum N] buffer)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
@@ -528,7 +528,7 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
 // Internal: convert up to 8 fp32 weight matrices to T (plain + transposed copies) in one launch.
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
                         const int* ldt, hipStream_t st) {
-    if (count < 1 || count > 8) return HYB_E_ARG;
+    if (count < 1 || count > 18) return HYB_E_ARG;      // up to three encoder layers in one launch
     ConvertArgs a{};
     int maxN = 0, maxK = 0;
     for (int i = 0; i < count; ++i) {

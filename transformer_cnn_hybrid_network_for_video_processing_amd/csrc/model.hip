@@ -176,6 +176,9 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
 // ----------------------------------------------------------------------------------------------------------
 // TransformerEncoder
 // ----------------------------------------------------------------------------------------------------------
+// Internal (fused.hip): where the first layer's input lives inside the saved blob -- a producer that writes there saves the copy
+size_t hyb_encoder_xin_offset(int dtype, int B, int S, int D, int Hid, int H) { return enc_layout(dtype, B, S, D, Hid, H).x_in; }
+
 extern "C" size_t hyb_encoder_saved_bytes(int dtype, int B, int S, int D, int Hid, int L, int H) {
     if (B <= 0 || S <= 0 || D <= 0 || Hid <= 0 || L <= 0 || H <= 0) return 0;
     return enc_layout(dtype, B, S, D, Hid, H).layer_bytes * (size_t)L;
@@ -198,13 +201,27 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
     const EncLayout lay = enc_layout(dtype, B, S, D, Hid, H);
     hipStream_t st = (hipStream_t)stream;
     char* sv = (char*)saved;
-    HYB_HIP_TRY(hipMemcpyAsync(sv + lay.x_in, x, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+    if ((const void*)x != (const void*)(sv + lay.x_in))       // (hyb_temporal_fwd writes the tokens there directly)
+        HYB_HIP_TRY(hipMemcpyAsync(sv + lay.x_in, x, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+    if (L <= 3) {   // the weight copies of every layer in ONE launch (they depend on the master weights only)
+        const float* Wsrc[18]; void* Wc[18]; void* Wt[18]; int Ns[18], Ks[18], ldt[18];
+        for (int i = 0; i < L; ++i) {
+            char* base = sv + (size_t)i * lay.layer_bytes;
+            const float* const* P = params + (size_t)i * 14;
+            const int n6[6] = {D, D, D, D, Hid, D}, k6[6] = {D, D, D, D, D, Hid}, l6[6] = {3 * D, 3 * D, 3 * D, D, Hid, D};
+            for (int j = 0; j < 6; ++j) {
+                Wsrc[i * 6 + j] = P[2 * j]; Wc[i * 6 + j] = base + lay.wc[j]; Wt[i * 6 + j] = base + lay.wt[j];
+                Ns[i * 6 + j] = n6[j]; Ks[i * 6 + j] = k6[j]; ldt[i * 6 + j] = l6[j];
+            }
+        }
+        HYB_TRY(hyb_convert_weights(dtype, 6 * L, Wsrc, Wc, Wt, Ns, Ks, ldt, st));
+    }
     for (int i = 0; i < L; ++i) {
         char* base = sv + (size_t)i * lay.layer_bytes;
         const float* const* P = params + (size_t)i * 14;
         void* x_in = base + lay.x_in;
         void* y_out = (i == L - 1) ? out : (void*)(base + lay.layer_bytes + lay.x_in);
-        {   // fp32 master weights -> T copies (plain for forward, transposed for dX), one launch per layer
+        if (L > 3) {   // fp32 master weights -> T copies (plain for forward, transposed for dX); deep stacks: one launch per layer
             const float* Wsrc[6] = {P[0], P[2], P[4], P[6], P[8], P[10]};
             void* Wc[6]; void* Wt[6];
             for (int j = 0; j < 6; ++j) { Wc[j] = base + lay.wc[j]; Wt[j] = base + lay.wt[j]; }
