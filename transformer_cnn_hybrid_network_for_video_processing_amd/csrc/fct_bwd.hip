@@ -239,13 +239,28 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
             if (want_cs && m == 0) cpart[(long long)blockIdx.y * Nn + n] = accs[i][r];
         }
 }
-// out[i] (+)= sum_s part[s][i], fixed order
-__global__ void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long n, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? out[i] : 0.f;
-    for (int j = 0; j < S; ++j) s += part[(long long)j * n + i];
-    out[i] = s;
+// out[i] (+)= sum_s part[s][i], fixed order: 256 threads = 32 columns x 8 slab groups (a column's slabs are split over 8 threads,
+// four loads in flight each, then combined through LDS) -- with ~2000 slabs a thread per column was a 2000-deep serial chain
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long n, int accumulate) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + col;
+    float a = 0.f;
+    if (i < n) {
+        int j = grp;
+        for (; j + 24 < S; j += 32) {
+            const float v0 = part[(long long)j * n + i], v1 = part[(long long)(j + 8) * n + i], v2 = part[(long long)(j + 16) * n + i],
+                        v3 = part[(long long)(j + 24) * n + i];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; j < S; j += 8) a += part[(long long)j * n + i];
+    }
+    red[grp][col] = a;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float t = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 // column sums over pixel slices: part[slice][c] = sum_{p in slice} v[p][c]   (block = 256 threads = 256/C.. generic: thread per column chunk)
 __global__ __launch_bounds__(256) void colsum_slice_kernel(const float* __restrict__ v, int ldv, float* __restrict__ part, long long P, int C,
@@ -533,36 +548,56 @@ int dispatch_cpl(int C, int& LPP, F&& f) {
 }  // namespace
 
 // Internal + used by fct MHA backward: out[Nn][K] (+)= dy^T x over P pixel rows, through SLICE_ROWS-row partial slabs in `ws`
-size_t hyb_sliced_wgrad_workspace(long long P, int Nn, int K) { return al256((size_t)hyb_cdiv(P, SLICE_ROWS) * Nn * K * 4); }
+// Slice length of the direct kernel: enough slices that (n groups) x (k groups) x slices is about 2048 workgroups -- the big feature
+// maps (800 k pixels) have 8 .. 16 channels, i.e. ONE (n, k) group: with 4096-row slices that was 196 workgroups on 256 CUs.
+static void direct_geometry(long long P, int Nn, int K, int& ntl, int& ktl, int& rows, int& S) {
+    ntl = Nn <= 16 ? 1 : 2;
+    ktl = K <= 32 ? 2 : K <= 64 ? 4 : 8;
+    const long long groups = (long long)hyb_cdiv(Nn, 16 * ntl) * hyb_cdiv(K, 16 * ktl);
+    long long r = (P * groups + 2047) / 2048;
+    r = (r + 15) / 16 * 16;
+    if (r < 128) r = 128;
+    if (r > SLICE_ROWS) r = SLICE_ROWS;
+    rows = (int)r;
+    S = (int)((P + r - 1) / r);
+}
+size_t hyb_sliced_wgrad_workspace(long long P, int Nn, int K) {
+    int ntl, ktl, rows, S;
+    direct_geometry(P, Nn, K, ntl, ktl, rows, S);
+    const int S1 = hyb_cdiv(P, SLICE_ROWS);                      // (first-generation kernel, HYB_FCT_WGRAD_V1)
+    return al256((size_t)(S > S1 ? S : S1) * Nn * K * 4);
+}
 template <int NTL, int KTL>
 static void launch_direct_wgrad(const float* dy, int lddy, const float* x, int ldx, float* part, float* cpart, long long P, int Nn, int K, int S,
-                                hipStream_t st) {
+                                int rows, hipStream_t st) {
     const int kgroups = hyb_cdiv(K, 16 * KTL), ngroups = hyb_cdiv(Nn, 16 * NTL);
     hipLaunchKernelGGL((direct_wgrad_kernel<NTL, KTL>), dim3(kgroups * ngroups, S), dim3(256), 0, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, kgroups,
-                       SLICE_ROWS);
+                       rows);
 }
 // out[Nn][K] (+)= dy^T x over P rows; colsum (optional, with its own partial workspace cws of hyb_sliced_colsum_workspace bytes):
 // colsum[Nn] (+)= column sums of dy, formed inside the same launch
 int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, float* out, float* colsum, long long P, int Nn, int K, int accumulate,
                         void* ws, void* cws, hipStream_t st) {
     static const int legacy = getenv("HYB_FCT_WGRAD_V1") ? atoi(getenv("HYB_FCT_WGRAD_V1")) : 0;      // first-generation kernel (A/B)
-    const int S = hyb_cdiv(P, SLICE_ROWS);
+    int ntl, ktl, rows, S;
+    direct_geometry(P, Nn, K, ntl, ktl, rows, S);
     float* cpart = colsum ? (float*)cws : nullptr;
     if (legacy) {
+        S = hyb_cdiv(P, SLICE_ROWS);
         const int tk = hyb_cdiv(K, 64), tn = hyb_cdiv(Nn, 64);
         hipLaunchKernelGGL(sliced_wgrad_kernel, dim3(tk * tn, S), dim3(256), 0, st, dy, lddy, x, ldx, (float*)ws, P, Nn, K, tk, SLICE_ROWS);
         if (colsum) hipLaunchKernelGGL(colsum_slice_kernel, dim3(S), dim3(256), 0, st, dy, lddy, cpart, P, Nn, SLICE_ROWS);
-    } else if (Nn <= 16) {
-        if (K <= 32) launch_direct_wgrad<1, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
-        else if (K <= 64) launch_direct_wgrad<1, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
-        else launch_direct_wgrad<1, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+    } else if (ntl == 1) {
+        if (ktl == 2) launch_direct_wgrad<1, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        else if (ktl == 4) launch_direct_wgrad<1, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        else launch_direct_wgrad<1, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
     } else {
-        if (K <= 32) launch_direct_wgrad<2, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
-        else if (K <= 64) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
-        else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, st);
+        if (ktl == 2) launch_direct_wgrad<2, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        else if (ktl == 4) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
     }
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid1((long long)Nn * K)), dim3(256), 0, st, (const float*)ws, out, S, (long long)Nn * K, accumulate);
-    if (colsum) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid1(Nn)), dim3(256), 0, st, (const float*)cpart, colsum, S, (long long)Nn, accumulate);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv((long long)Nn * K, 32)), dim3(256), 0, st, (const float*)ws, out, S, (long long)Nn * K, accumulate);
+    if (colsum) hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv(Nn, 32)), dim3(256), 0, st, (const float*)cpart, colsum, S, (long long)Nn, accumulate);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -570,11 +605,17 @@ int hyb_sliced_wgrad(const float* dy, int lddy, const float* x, int ldx, float* 
                      hipStream_t st) {
     return hyb_sliced_wgrad_cs(dy, lddy, x, ldx, out, nullptr, P, Nn, K, accumulate, ws, nullptr, st);
 }
-size_t hyb_sliced_colsum_workspace(long long P, int C) { return al256((size_t)hyb_cdiv(P, SLICE_ROWS) * C * 4); }
+// (also the bias-gradient partials of hyb_sliced_wgrad_cs, whose slices are at least 128 rows and at most ~2048 + 1 in number)
+size_t hyb_sliced_colsum_workspace(long long P, int C) {
+    long long S = hyb_cdiv(P, 128);
+    if (S > 2064) S = 2064;
+    const long long S1 = hyb_cdiv(P, SLICE_ROWS);
+    return al256((size_t)(S > S1 ? S : S1) * C * 4);
+}
 int hyb_sliced_colsum(const float* v, int ldv, float* out, long long P, int C, int accumulate, void* ws, hipStream_t st) {
     const int S = hyb_cdiv(P, SLICE_ROWS);
     hipLaunchKernelGGL(colsum_slice_kernel, dim3(S), dim3(256), 0, st, v, ldv, (float*)ws, P, C, SLICE_ROWS);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid1(C)), dim3(256), 0, st, (const float*)ws, out, S, (long long)C, accumulate);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, out, S, (long long)C, accumulate);
     HYB_LAUNCH_CHECK();
     return 0;
 }
