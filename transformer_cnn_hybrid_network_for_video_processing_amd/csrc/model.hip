@@ -188,7 +188,9 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const size_t M = (size_t)B * S;
     const size_t big = (size_t)(Hid > D ? Hid : D);
-    return 8 * align256(M * D * es) + 2 * align256(M * big * es) + align256((size_t)2 * 32 * 2 * D * sizeof(float));      // + LayerNorm partial rows
+    // (the buffers a layer's weight gradients read -- g1, dqkv, dh, g1b, LayerNorm partial rows -- exist twice: with the side stream
+    // the gradients of layer i are still being formed while layer i-1 runs)
+    return 12 * align256(M * D * es) + 4 * align256(M * big * es) + 2 * align256((size_t)2 * 32 * 2 * D * sizeof(float));
 }
 
 extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
@@ -263,16 +265,29 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
     const char* sv = (const char*)saved;
     char* ws = (char*)workspace;
     const size_t md = align256((size_t)M * D * es);
-    void* g1 = ws;            // d(LN input)
-    void* g2 = ws + md;       // d(x1)
-    void* g4 = ws + 2 * md;   // d(attn)
-    void* dqkv = ws + 3 * md; // d(q|k|v) packed [M][3D] (3 * md bytes reserved)
-    void* gin[2] = {ws + 6 * md, ws + 7 * md};
     const size_t big = align256((size_t)M * (Hid > D ? Hid : D) * es);
-    void* dh = ws + 8 * md;             // d(hmid)
-    void* g1b = ws + 8 * md + big;      // d(LN1 input): its own buffer so that all six dW inputs of a layer are alive at its end
-    float* lnpart = (float*)(ws + 8 * md + 2 * big);     // LayerNorm affine-gradient partial rows of the layer's two calls
+    const size_t lnb = align256((size_t)2 * 32 * 2 * D * sizeof(float));
     const int lnrows = hyb_ln_bwd_rows(M);
+    // shared by all layers (consumed inside a layer's dX chain)
+    void* g2 = ws;            // d(x1)
+    void* g4 = ws + md;       // d(attn)
+    void* gin[2] = {ws + 2 * md, ws + 3 * md};
+    // per layer parity: what the layer's weight-gradient launch reads
+    struct Set { void* g1; void* dqkv; void* dh; void* g1b; float* lnpart; } set[2];
+    {
+        char* q = ws + 4 * md;
+        for (int j = 0; j < 2; ++j) {
+            set[j].g1 = q; q += md;                 // d(LN2 input)
+            set[j].dqkv = q; q += 3 * md;           // d(q|k|v) packed [M][3D]
+            set[j].dh = q; q += big;                // d(hmid)
+            set[j].g1b = q; q += big;               // d(LN1 input)
+            set[j].lnpart = (float*)q; q += lnb;    // LayerNorm affine-gradient partial rows of the layer's two calls
+        }
+    }
+    // Off the dX chain: the layer's LayerNorm-affine reduce and its six weight (+ bias) gradients.  While the stream is being captured
+    // they go to the side stream (a parallel graph branch beside the next layer's latency-bound chain); otherwise they stay in line.
+    HybSide* side = hyb_side_for(st);
+    bool pending[2] = {false, false};
 
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
@@ -280,42 +295,57 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         const float* const* P = params + (size_t)i * 14;
         float* const* G = grads + (size_t)i * 14;
         void* gx = (i == 0) ? dx : gin[i & 1];
+        const Set& b = set[i & 1];
+        if (side && pending[i & 1]) {               // layer i+2's gradients still read this parity's buffers
+            HYB_HIP_TRY(hipStreamWaitEvent(st, side->done[i & 1], 0));
+            pending[i & 1] = false;
+        }
         // LN2 + residual + sqrt(.5) + dropout
-        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), g1, g2, 0, lnpart, M, D,
+        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), b.g1, g2, 0, b.lnpart, M, D,
                                          (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, st));
-        // FFN second Linear: dX = g1 . W2 (pre-transposed copy), dW/db in one launch
-        { const void* A_[1] = {g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {dh};
+        // FFN second Linear: dX = g1 . W2 (pre-transposed copy)
+        { const void* A_[1] = {b.g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {b.dh};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
         // FFN first Linear (+ReLU): the mask (hmid > 0) is applied inside the GEMM loaders
-        { const void* A_[1] = {dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
+        { const void* A_[1] = {b.dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
         // LN1 + residual
-        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), g1b, gx, 0,
-                                         lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, nullptr, st));
-        // the layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients, fixed order
-        HYB_TRY(hyb_ln_rows_reduce(lnpart, 2 * lnrows, D, G[12], G[13], st));
+        HYB_TRY(hyb_ln_residual_bwd_rows(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), b.g1b, gx, 0,
+                                         b.lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, nullptr, st));
         // output projection
-        { const void* A_[1] = {g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
+        { const void* A_[1] = {b.g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
         // attention core: d(q|k|v) packed [M][3D]
-        HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, dqkv, B, S, D, H, attn_p,
+        HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, b.dqkv, B, S, D, H, attn_p,
                                          attn_seed(seed, i), seed_inc, st));
-        // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM, one grouped dW/db launch
-        { const void* A_[1] = {dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
+        // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM
+        { const void* A_[1] = {b.dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }
+        hipStream_t ws_st = st;
+        if (side) {                                 // fork: everything the gradients read has been enqueued on `st`
+            HYB_HIP_TRY(hipEventRecord(side->fork, st));
+            HYB_HIP_TRY(hipStreamWaitEvent(side->s, side->fork, 0));
+            ws_st = side->s;
+        }
+        // the layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients, fixed order
+        HYB_TRY(hyb_ln_rows_reduce(b.lnpart, 2 * lnrows, D, G[12], G[13], ws_st));
         // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches)
         {
-            const char* dq_ = (const char*)dqkv; const char* qk_ = base + lay.qkv;
-            const void* dy_[6] = {g1, dh, g1b, dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
+            const char* dq_ = (const char*)b.dqkv; const char* qk_ = base + lay.qkv;
+            const void* dy_[6] = {b.g1, b.dh, b.g1b, dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
             const void* mk_[6] = {nullptr, base + lay.hmid, nullptr, qk_, qk_ + (size_t)D * es, qk_ + 2 * (size_t)D * es};
             const void* x_[6] = {base + lay.hmid, base + lay.x1, base + lay.attn, base + lay.x_in, base + lay.x_in, base + lay.x_in};
             float* dW_[6] = {G[10], G[8], G[6], G[0], G[2], G[4]};
             float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
             const int N_[6] = {D, Hid, D, D, D, D}, K_[6] = {Hid, D, D, D, D, D};
             const int lddy_[6] = {D, Hid, D, 3 * D, 3 * D, 3 * D}, ldx_[6] = {Hid, D, D, D, D, D};
-            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st));
+            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, ws_st));
         }
+        if (side) { HYB_HIP_TRY(hipEventRecord(side->done[i & 1], side->s)); pending[i & 1] = true; }
         gA = gx;
     }
+    if (side)                                       // join: the caller's stream continues after every gradient launch
+        for (int j = 0; j < 2; ++j)
+            if (pending[j]) HYB_HIP_TRY(hipStreamWaitEvent(st, side->done[j], 0));
     return 0;
 }
