@@ -558,13 +558,29 @@ __device__ __forceinline__ void ff_zero(Frag16<float>& f) { f.v[0] = f.v[1] = f.
 __device__ __forceinline__ void ff_zero(Frag<bf16>& f) { frag_zero(f); }
 __device__ __forceinline__ f32x4 ff_mma(const Frag16<float>& a, const Frag16<float>& b, f32x4 c) { return mma16(a, b, c); }
 __device__ __forceinline__ f32x4 ff_mma(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) { return mma32(a, b, c); }
+// narrowest fp32 step: 8 features = two 16x16x4 MFMAs, 2 consecutive features per lane -- heads of 4 (padded to 8) and 8 features, which
+// are FCT's 12 544- and 3 136-token attentions (where the time goes)
+struct Frag8f { float v[2]; };
+__device__ __forceinline__ void ff_load(Frag8f& f, const float* p) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ a = *reinterpret_cast<const f32x2_*>(p);
+    f.v[0] = a[0]; f.v[1] = a[1];
+}
+__device__ __forceinline__ void ff_zero(Frag8f& f) { f.v[0] = f.v[1] = 0.f; }
+__device__ __forceinline__ f32x4 ff_mma(const Frag8f& a, const Frag8f& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[0], b.v[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[1], b.v[1], c, 0, 0, 0);
+}
+template <typename T, int FWP> struct FeatSel { typedef typename Feat<T>::F F; static constexpr int W = Feat<T>::W; };
+template <> struct FeatSel<float, 8> { typedef Frag8f F; static constexpr int W = 8; };
+
 template <typename T, typename F>
 __device__ __forceinline__ void ff_row(F& f, const T* row, int f0, int dhp) {      // features f0 .. of one row (global or LDS)
     if (f0 < dhp) ff_load(f, row + f0);
     else ff_zero(f);
 }
 
-template <typename T>
+template <typename T, int FWP = 0 /* 8: the 8-feature fp32 step (dhp == 8 only) */>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
                                                            float* __restrict__ lse, int L, int H, int dhp, int ld, int ldi, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -575,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    using FF = typename Feat<T>::F;
-    constexpr int FW = Feat<T>::W, FL = FW / 4, MAXFS = 16 * MAXDT / FW;       // step width, features per lane and step, most steps
+    using FF = typename FeatSel<T, FWP>::F;
+    constexpr int FW = FeatSel<T, FWP>::W, FL = FW / 4, MAXFS = FWP == 8 ? 1 : 16 * MAXDT / FW;      // step width, features per lane and step, most steps
     const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int query = blockIdx.x * 64 + wave * 16 + p;
     const int qrow = query < L ? query : L - 1;
@@ -671,7 +687,7 @@ __global__ void flash_delta_kernel(const T* __restrict__ o, const T* __restrict_
 }
 
 // dQ: workgroup = 64 queries (4 waves x 16) of one (image, head); loops over 64-key blocks staged in LDS (K and V images).
-template <typename T, int DTC>
+template <typename T, int DTC, int FWP = 0>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                               const T* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, T* __restrict__ dq, int L, int H, int dhp, int ld,
@@ -684,12 +700,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    using FF = typename Feat<T>::F;
-    constexpr int FW = Feat<T>::W, FL = FW / 4;
+    using FF = typename FeatSel<T, FWP>::F;
+    constexpr int FW = FeatSel<T, FWP>::W, FL = FW / 4;
     const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int query = blockIdx.x * 64 + wave * 16 + p;
     const int qrow = query < L ? query : L - 1;
-    constexpr int KSC = (DTC * 16 + FW - 1) / FW;
+    constexpr int KSC = FWP == 8 ? 1 : (DTC * 16 + FW - 1) / FW;
     FF fq[KSC], fg[KSC];
 #pragma unroll
     for (int s = 0; s < KSC; ++s)
@@ -756,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
 }
 
 // dK, dV: workgroup = 64 keys (4 waves x 16) of one (image, head); loops over 64-query blocks staged in LDS (Q and dO images + lse, delta).
-template <typename T, int DTC>
+template <typename T, int DTC, int FWP = 0>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                                const T* __restrict__ dout, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv, int L,
@@ -771,12 +787,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
     const int p = lane & 15, g = lane >> 4;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * dhp;
-    using FF = typename Feat<T>::F;
-    constexpr int FW = Feat<T>::W, FL = FW / 4;
+    using FF = typename FeatSel<T, FWP>::F;
+    constexpr int FW = FeatSel<T, FWP>::W, FL = FW / 4;
     const int DT = (dhp + 15) >> 4, ks = (dhp + FW - 1) / FW, segs = dhp >> 3;
     const int key = blockIdx.x * 64 + wave * 16 + p;
     const int krow = key < L ? key : L - 1;
-    constexpr int KSC = (DTC * 16 + FW - 1) / FW;
+    constexpr int KSC = FWP == 8 ? 1 : (DTC * 16 + FW - 1) / FW;
     FF fk[KSC], fv[KSC];
 #pragma unroll
     for (int s = 0; s < KSC; ++s)
@@ -864,7 +880,8 @@ int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void*
     const dim3 grid(hyb_cdiv(L, 64), N * H);
     if (dtype == HYB_F32) {
         if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)flash_fwd_kernel<float>, 160 * 1024)) return e; }
-        hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
+        if (dhp == 8) hipLaunchKernelGGL((flash_fwd_kernel<float, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
+        else hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
     } else if (dtype == HYB_BF16) {
         hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, L, H, dhp, ld, ldi, scale);
     } else return HYB_E_ARG;
@@ -892,7 +909,12 @@ int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void*
         hipLaunchKernelGGL((flash_bwd_dkv_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \
                            (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale); } while (0)
     const int DT = (dhp + 15) / 16;
-    if (DT <= 1) FLASH_BWD(1); else if (DT <= 2) FLASH_BWD(2); else if (DT <= 4) FLASH_BWD(4); else FLASH_BWD(8);
+    if (dhp == 8) {
+        hipLaunchKernelGGL((flash_bwd_dq_kernel<float, 1, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale);
+        hipLaunchKernelGGL((flash_bwd_dkv_kernel<float, 1, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale);
+    } else if (DT <= 1) FLASH_BWD(1); else if (DT <= 2) FLASH_BWD(2); else if (DT <= 4) FLASH_BWD(4); else FLASH_BWD(8);
 #undef FLASH_BWD
     HYB_LAUNCH_CHECK();
     return 0;
