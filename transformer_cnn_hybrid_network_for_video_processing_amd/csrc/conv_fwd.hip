@@ -442,7 +442,9 @@ __global__ __launch_bounds__(1024) void stats_reduce_kernel(const float* __restr
 
 constexpr int MAX_STAT_PARTIALS = 512;
 }  // namespace
-int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st);   // conv_v2.hip
+int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st,
+                long long xblk = 0);   // conv_v2.hip
+int hyb_conv_v2_supported(int W, int Cip, int Cop);
 namespace {
 
 template <typename T, int NT, int CB, int PG, int CK, bool WLDS = false>
@@ -552,6 +554,20 @@ int conv_fwd_t(int first, const void* x, const void* wp, void* y, float* stats, 
 }
 
 }  // namespace
+
+// Internal (hyb_convstage_bwd): does the bf16 dgrad conv of this shape run on the asynchronous kernel (which can read a block-planar input)?
+int hyb_conv_dgrad_planar_ok(int dtype, int W, int Cin_p, int Cout_p) {
+    static const int v2 = getenv("HYB_CONV_V2") ? atoi(getenv("HYB_CONV_V2")) : 1;
+    return dtype == HYB_BF16 && v2 && hyb_conv_v2_supported(W, Cin_p, Cout_p);
+}
+// Internal: conv3x3 (dgrad weights) of a block-planar bf16 input [Cin_p/32][N][H][W][32] -> NHWC output
+int hyb_conv3x3_planar_in(const void* x, const void* wp, void* y, int N, int H, int W, int Cin_p, int Cout_p, hipStream_t st) {
+    HybProfileHook* hook = hyb_find_hook(1, Cin_p, Cout_p);
+    if (hook) hipEventRecord(hook->ev0, st);
+    const int rc = hyb_conv_v2(x, wp, y, nullptr, N, H, W, Cin_p, Cout_p, 0, st, (long long)N * H * W * 32);
+    if (hook) hipEventRecord(hook->ev1, st);
+    return rc;
+}
 
 extern "C" long long hyb_conv_packed_elems(int first, int Cip, int Cop) {
     return first ? (long long)Cop * 32 : (long long)Cop * 9 * Cip;

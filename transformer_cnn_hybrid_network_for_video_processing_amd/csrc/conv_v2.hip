@@ -73,7 +73,9 @@ template <int NT, int CB, int PGR, int PGC, int R, bool STATS>
 __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) void conv3x3_v2_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp,
                                                             bf16* __restrict__ y, float* __restrict__ stats,
                                                             int N, int H, int W, int Cip, int Cop,
-                                                            int tilesX, int tilesY, int numTiles, int stat_rows) {
+                                                            int tilesX, int tilesY, int numTiles, int stat_rows, int xpix, long long xblk) {
+    // input addressing: element stride between pixels (Cip for NHWC) and between 32-channel blocks (32 for NHWC); a "block-planar"
+    // input [Cip/32][N][H][W][32] has xpix = 32, xblk = N*H*W*32: a block's halo then uses whole 128-byte lines (see hyb_convstage_bwd)
     using G = V2Geom<NT, CB, PGR, PGC, R>;
     constexpr int MT = G::MT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, HT = G::HT, NHW = G::NHW;
     constexpr int CBW = G::CBW, WSLOT = G::WSLOT, NWW = G::NWW, WI = G::WI, PG = G::PG, NW = G::NW, NTHR = NW * 64;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
         const int u = wi * 64 + lane, hp = u >> 2, sp = u & 3;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int s = sp ^ ((hy & 1) << 1);                                     // halo swizzle for 32-channel pixels
-        if (HOFF_REG) hoff[k] = (unsigned)(((hy * W + hx) * Cip + s * 8) * 2);
+        if (HOFF_REG) hoff[k] = (unsigned)(((hy * W + hx) * xpix + s * 8) * 2);
         hyx[k] = hp < HP ? ((hy << 20) | (hx << 4) | s) : (0x7ff << 20);
     }
     // ---- weight DMA pieces of this lane: byte offset inside this workgroup's CBW packed rows
@@ -142,14 +144,14 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
     // descriptor of a block's halo: base = the halo origin pixel (may lie before the tensor for border tiles: such lanes are
     // sent out of range and never dereference it)
     auto halo_rsrc = [&](const Blk& b) {
-        const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * Cip + b.cblk * 32;
+        const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * xpix + b.cblk * xblk;
         return hyb_rsrc((x + base), V2_RECORDS);
     };
     auto halo_piece = [&](const Blk& b, __amdgpu_buffer_rsrc_t rs, bf16* hb, int k) {
         const int hy = hyx[k] >> 20, hx = (hyx[k] >> 4) & 0xffff;
         const int gy = b.ty0 - 1 + hy, gx = b.tx0 - 1 + hx;
         const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-        const unsigned off = HOFF_REG ? hoff[HOFF_REG ? k : 0] : (unsigned)(((hy * W + hx) * Cip + (hyx[k] & 15) * 8) * 2);
+        const unsigned off = HOFF_REG ? hoff[HOFF_REG ? k : 0] : (unsigned)(((hy * W + hx) * xpix + (hyx[k] & 15) * 8) * 2);
         int wi = k * NW + wave;
         if (wi > NHW - 1) wi = NHW - 1;
         dma16(rs, valid ? off : V2_OOB, 0, hb + wi * 512);
@@ -350,7 +352,8 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
 }
 
 template <int NT, int CB, int PGR, int PGC, int R>
-int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st) {
+int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st, int xpix,
+              long long xblk) {
     using G = V2Geom<NT, CB, PGR, PGC, R>;
     const int tilesX = hyb_cdiv(W, G::TW), tilesY = hyb_cdiv(H, G::TH);
     const long long numTiles = (long long)N * tilesX * tilesY;
@@ -365,10 +368,10 @@ int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H,
     if (int e = hyb_set_lds_attr(once_plain, (const void*)conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>, (int)G::LDS_BYTES)) return e;
     if (part)
         hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, true>), grid, dim3(G::NW * 64), G::LDS_BYTES, st, x, wp, y, part, N, H, W, Cip, Cop,
-                           tilesX, tilesY, (int)numTiles, stat_rows);
+                           tilesX, tilesY, (int)numTiles, stat_rows, xpix, xblk);
     else
         hipLaunchKernelGGL((conv3x3_v2_kernel<NT, CB, PGR, PGC, R, false>), grid, dim3(G::NW * 64), G::LDS_BYTES, st, x, wp, y, (float*)nullptr, N, H, W,
-                           Cip, Cop, tilesX, tilesY, (int)numTiles, 0);
+                           Cip, Cop, tilesX, tilesY, (int)numTiles, 0, xpix, xblk);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -384,10 +387,18 @@ double v2_cost(int N, int H, int W, int TH, int TW, int gy) {
 
 // Internal (conv_fwd.hip): returns -100 when no asynchronous variant fits this shape.  part: partial-statistics rows
 // [stat_rows][2][Cop] (may be NULL), all of them written.
-int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st) {
+// which shapes hyb_conv_v2 takes (the same tests as below)
+int hyb_conv_v2_supported(int W, int Cip, int Cop) {
+    return !(Cip % 32 != 0 || (long long)40 * W * Cip >= (1ll << 29) || (long long)256 * 9 * Cip >= (1ll << 29)) && Cop % 32 == 0;
+}
+
+// xblk = 0: NHWC input; else the block-planar input's block stride in elements (see conv3x3_v2_kernel)
+int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st, long long xblk) {
+    const int xpix = xblk ? 32 : Cip;
+    if (!xblk) xblk = 32;
     if (Cip % 32 != 0 || (long long)40 * W * Cip >= (1ll << 29) || (long long)256 * 9 * Cip >= (1ll << 29)) return -100;   // 32-bit buffer offsets
     const bf16* xb = (const bf16*)x; const bf16* wb = (const bf16*)wp; bf16* yb = (bf16*)y;
-#define V2(NT_, CB_, PGR_, PGC_, R_) launch_v2<NT_, CB_, PGR_, PGC_, R_>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st)
+#define V2(NT_, CB_, PGR_, PGC_, R_) launch_v2<NT_, CB_, PGR_, PGC_, R_>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st, xpix, xblk)
     // Measured on the 224 x 224 clip stages: two four-wave workgroups per CU (their epilogues and MFMA phases interleave) win for
     // Cop <= 128; 256-channel blocks need the whole CU's LDS for a deep weight ring.  HYB_V2_NW=4|8 forces one family.
     static const int nw_env = getenv("HYB_V2_NW") ? atoi(getenv("HYB_V2_NW")) : 0;

@@ -48,6 +48,7 @@ struct WgradFuse {
     const float* gamma;     // [Co]
     const float* sums;      // [2][Cop]: sum dy, sum dy*xhat
     void* dyraw_out;        // optional: dense gradient written once (by the ci-block 0 workgroups) for the dgrad conv
+    long long dyraw_blk;    // 0: NHWC [N][H][W][Cop]; else block-planar [Cop/32][N][H][W][32] with this block stride in elements (v2 kernel only)
     int Co, training;
     float inv_count;
 };
@@ -433,6 +434,17 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
             for (int j = 0; j < 4; ++j) yoff[i][j] = (unsigned)((((2 * uwy[i] + (j >> 1)) * W + 2 * uwx[i] + (j & 1)) * Cop + 8 * uoct[i]) * 2);
             goff[i] = (unsigned)(((uwy[i] * (W >> 1) + uwx[i]) * Cop + 8 * uoct[i]) * 2);
         }
+        // dyraw store offsets: NHWC = the y load offsets; block-planar: pixel stride 32 channels, this lane's 32-channel half of the
+        // workgroup's 64 output channels at + dyraw_blk
+        const bool planar = FUSE && fz.dyraw_blk != 0;
+        unsigned ooff[NU][4];
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ooff[i][j] = planar ? (unsigned)((((2 * uwy[i] + (j >> 1)) * W + 2 * uwx[i] + (j & 1)) * 32 + 8 * (uoct[i] & 3)) * 2 +
+                                                 (uoct[i] >> 2) * fz.dyraw_blk * 2)
+                                    : yoff[i][j];
         const bool writer = FUSE && fz.dyraw_out && ci0 == 0;
         auto fuse_load = [&](const W2Tile& t, W2Unit (&un)[NU]) {
             const int Ho = H >> 1, Wo = W >> 1;
@@ -451,7 +463,8 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
             }
         };
         auto fuse_compute = [&](const W2Tile& t, W2Unit (&un)[NU], bf16* db) {
-            const long long ybase = ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
+            const long long ybase = planar ? ((long long)(t.n * H + t.ty0) * W + t.tx0) * 32 + (long long)(co0 / 32) * fz.dyraw_blk
+                                           : ((long long)(t.n * H + t.ty0) * W + t.tx0) * Cop + co0;
             const __amdgpu_buffer_rsrc_t o_rs = hyb_rsrc((bf16*)fz.dyraw_out + ybase, writer ? W2_RECORDS : 0u);
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -480,7 +493,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
                 for (int j = 0; j < 4; ++j) {
                     const int ly = 2 * uwy[i] + (j >> 1), lx = 2 * uwx[i] + (j & 1);
                     *reinterpret_cast<bf16x8*>(db + (ly * W2_TW + lx) * 64 + ((uoct[i] ^ w2_swz(ly, lx)) << 3)) = o[j].v;
-                    __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, un[i].pv[j] ? yoff[i][j] : W2_OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, un[i].pv[j] ? ooff[i][j] : W2_OOB, 0, 0);
                 }
             }
         };
@@ -730,10 +743,18 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
 }  // namespace
 
 // Internal: weight gradient with the BatchNorm/ReLU/MaxPool backward fused into the tile staging (non-first stages)
+// which shapes take the warp-specialised kernel (the only one that can write a block-planar dyraw): the tests of wgrad_t
+int hyb_wgrad_v2_supported(int dtype, int W, int Cip, int Cop) {
+    static const int v2 = getenv("HYB_WGRAD_V2") ? atoi(getenv("HYB_WGRAD_V2")) : 1;
+    const int ci_blk = Cip % 64 == 0 ? 64 : 32;
+    return dtype == HYB_BF16 && v2 && Cip % 32 == 0 && Cop % 64 == 0 && (Cop / 64) * (Cip / ci_blk) <= 256 &&
+           (long long)12 * W * (Cip > Cop ? Cip : Cop) < (1ll << 29);
+}
+
 int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
-                            const float* sums, int training, long long count, void* dyraw_out, float* dw, int N, int H, int W, int Ci,
-                            int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st) {
-    WgradFuse fz{y, dp, ss, mi, gamma, sums, dyraw_out, Co, training, 1.0f / (float)count};
+                            const float* sums, int training, long long count, void* dyraw_out, long long dyraw_blk, float* dw, int N, int H, int W,
+                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    WgradFuse fz{y, dp, ss, mi, gamma, sums, dyraw_out, dyraw_blk, Co, training, 1.0f / (float)count};
     if (dtype == HYB_F32) return wgrad_t<float>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
     if (dtype == HYB_BF16) return wgrad_t<bf16>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
     return HYB_E_ARG;

@@ -3,6 +3,7 @@
 //   hyb_convstage_{fwd,bwd} : Conv3x3 -> BatchNorm2d -> ReLU -> MaxPool2d      (UNet.py:58-60, UNet.py:13)
 //   hyb_encoder_{fwd,bwd}   : TransformerEncoder.forward, all layers             (TransformerEncoder.pyc src L110-126)
 #include <math.h>
+#include <stdlib.h>
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
@@ -37,8 +38,11 @@ int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* 
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
                    float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
 int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
-                            const float* sums, int training, long long count, void* dyraw_out, float* dw, int N, int H, int W, int Ci,
-                            int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st);
+                            const float* sums, int training, long long count, void* dyraw_out, long long dyraw_blk, float* dw, int N, int H, int W,
+                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st);
+int hyb_wgrad_v2_supported(int dtype, int W, int Cip, int Cop);
+int hyb_conv_dgrad_planar_ok(int dtype, int W, int Cin_p, int Cout_p);
+int hyb_conv3x3_planar_in(const void* x, const void* wp, void* y, int N, int H, int W, int Cin_p, int Cout_p, hipStream_t st);
 int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, int Co, int Ci, int Cop, int Cip, hipStream_t st);
 
 namespace {
@@ -162,13 +166,20 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     const long long count = (long long)N * H * W;
     HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, pooled, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
     // dense BN/ReLU/pool backward is computed inside the wgrad tile staging; the tile is also written once (dyraw) for dgrad
-    HYB_TRY(hyb_conv3x3_wgrad_fused(dtype, x, y_raw, dpooled, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dweight, N, H, W,
-                                    Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream));
+    // Layout of the dense gradient between the two kernels.  NHWC makes the dgrad conv read each 128-byte line of a >= 64-channel
+    // gradient once per 32-channel block (stage 2: 555 MB fetched for 308 MB, by PMC); when both kernels are the second-generation
+    // ones the tensor is written block-planar, [Cop/32][N][H][W][32], and a block's halo uses whole lines.
+    static const int planar_env = getenv("HYB_DYRAW_PLANAR") ? atoi(getenv("HYB_DYRAW_PLANAR")) : 1;
+    const bool planar = planar_env && !first && Cop >= 64 && hyb_wgrad_v2_supported(dtype, W, Cip, Cop) && hyb_conv_dgrad_planar_ok(dtype, W, Cop, Cip);
+    const long long dyraw_blk = planar ? (long long)N * H * W * 32 : 0;
+    HYB_TRY(hyb_conv3x3_wgrad_fused(dtype, x, y_raw, dpooled, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dyraw_blk, dweight, N, H,
+                                    W, Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream));
     if (!first) {
         // dgrad = conv3x3 of the dense output gradient with the transposed, tap-flipped weights
         const void* wd = packed_bwd;
         if (!wd) { HYB_TRY(hyb_conv_pack_weight(dtype, 1, weight, wpd, Co, Ci, Cop, Cip, stream)); wd = wpd; }
-        HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wd, dx, nullptr, nullptr, N, H, W, Co, Cop, Cip, stream));
+        if (planar) HYB_TRY(hyb_conv3x3_planar_in(dyraw, wd, dx, N, H, W, Cop, Cip, (hipStream_t)stream));
+        else HYB_TRY(hyb_conv3x3_fwd(dtype, 0, dyraw, wd, dx, nullptr, nullptr, N, H, W, Co, Cop, Cip, stream));
     }
     return 0;
 }
