@@ -438,7 +438,8 @@ inline bool attn_dims(AttnDims& d, int B, int S, int D, int H, size_t es) {
     d.ld_qkv = D;
     d.ld_o = D;
     // a grid of one-wave workgroups is dispatch-bound beyond a few thousand problems: pack four single-tile problems per workgroup then
-    d.ppw = (d.nt == 1 && (long long)B * H >= 2048) ? 4 : 1;
+    static const int ppw_env = getenv("HYB_ATTN_PPW") ? atoi(getenv("HYB_ATTN_PPW")) : 4;      // waves (= problems) per workgroup at S <= 16
+    d.ppw = (d.nt == 1 && (long long)B * H >= 2048) ? (ppw_env >= 1 && ppw_env <= 16 ? ppw_env : 4) : 1;
     return true;
 }
 
