@@ -20,9 +20,20 @@ namespace {
 // Same fragment scheme, K order, packed weights, partial-row layout and results as the block-level kernel, which remains the path for
 // row strides that are not a multiple of 4 floats and for tensors of 4 GiB and more (32-bit buffer offsets).
 constexpr int S1W_BW = 16;                       // block width: two 8x8 sub-blocks side by side
-constexpr int S1W_R = 28;                        // LDS image row stride in pixels (24 used); 2 rows = 448 B = 48 banks past a multiple of 64
+// LDS image layout: rows come in PAIRS -- row 2i at pixel PAIR * i, row 2i+1 at PAIR * i + ODD (24 pixels of 8 / 16 bytes used per
+// row; both offsets even so that rows stay 16-byte aligned for the staging stores).  With 8-byte pixel quads no linear row stride keeps
+// the 2-pixel-strided fragment reads, the transposing reads and the staging stores off each other's banks; a bank model of the access
+// patterns prefers 88 / 42 to the linear 28-pixel stride (= 56 / 28) by 13 %.  Measured (same box, alternating builds): 1.4549 vs
+// 1.4580 ms per step -- inside the noise: LDS conflicts are not what these kernels wait for.  A row index that is "lane part + even
+// compile-time part" still splits into a per-lane constant plus an immediate: rowoff(a + 2e) = rowoff(a) + PAIR * e.
+#ifndef S1W_PAIR_PX
+#define S1W_PAIR_PX 88          /* -DS1W_PAIR_PX=56 -DS1W_ODD_PX=28 is the linear 28-pixel stride (A/B: scripts/s1_layout_ab.sh) */
+#define S1W_ODD_PX 42
+#endif
+constexpr int S1W_PAIR = S1W_PAIR_PX, S1W_ODD = S1W_ODD_PX;
+__host__ __device__ constexpr int s1w_rowoff(int r) { return (r >> 1) * S1W_PAIR + (r & 1) * S1W_ODD; }
 constexpr int S1W_ROWS = 10;
-constexpr int S1W_IMG = S1W_ROWS * S1W_R * 4;    // elements per buffer
+constexpr int S1W_IMG = (S1W_ROWS / 2) * S1W_PAIR * 4;   // elements per buffer
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
     const int hrow = lane / 6, hseg = lane - hrow * 6;
     const bool hlane = lane < 60;
     const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);                         // bytes from the block's halo origin
-    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);                      // element offset of this lane's 4 pixels in an image buffer
+    const unsigned st_lds = (unsigned)((s1w_rowoff(hrow) + 4 * hseg) * 4);                      // element offset of this lane's 4 pixels in an image buffer
     const unsigned plane = (unsigned)(H * W) * 4u;                                          // channel plane in bytes
     const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
     const unsigned OOB = 0xFFFFFFF0u;
@@ -100,8 +111,12 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
     // 16-byte run of the image -- a single ds_read2_b64 straight into the MFMA operand registers, no assembly moves.
     //   k-step 0: q = 0,1,2 -> taps (q,0),(q,1);  q = 3 -> tap (0,2) + the pixel right of the window (zero weights)
     //   k-step 1: q = 0 -> tap (1,2), q = 1 -> tap (2,2) (+ zero-weight neighbours); q = 2,3 read q = 1's address (zero weights)
-    const int f_k0 = ((2 * wy + (q < 3 ? q : 0)) * S1W_R + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
-    const int f_k1 = ((2 * wy + (q == 0 ? 1 : 2)) * S1W_R + 2 * wx + 3 + 2) * 4;
+    int f_k0[2], f_k1[2];                                                      // [jy]: window rows 2 wy + jy
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+        f_k0[jy] = (s1w_rowoff(2 * wy + jy + (q < 3 ? q : 0)) + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
+        f_k1[jy] = (s1w_rowoff(2 * wy + jy + (q == 0 ? 1 : 2)) + 2 * wx + 3 + 2) * 4;
+    }
     // pooled store (MODE 1): bytes from the block's first window, for sub-block 0
     const unsigned po_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
     const __amdgpu_buffer_rsrc_t prs = hyb_rsrc(MODE == 1 ? a.pooled : (void*)a.x, MODE == 1 ? (unsigned)((long long)a.N * Ho * Wo * Cop * (int)sizeof(T)) : 16u);
@@ -150,15 +165,15 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
         // the fragments of window positions jx = 0 and jx = 1 overlap by one pixel; left alone the compiler reads every pixel once and
         // assembles the second fragment with register moves -- VALU work on the critical resource to save LDS bandwidth that is idle.
         // An opaque copy of the offset keeps the two reads separate: each fragment is one ds_read2_b64 into its operand registers.
-        int fx0[2] = {f_k0, f_k0 + 4}, fx1[2] = {f_k1, f_k1 + 4};
-        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]));
+        int fx0[4] = {f_k0[0], f_k0[0] + 4, f_k0[1], f_k0[1] + 4}, fx1[4] = {f_k1[0], f_k1[0] + 4, f_k1[1], f_k1[1] + 4};      // [j = 2 jy + jx]
+        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]), "+v"(fx0[3]), "+v"(fx1[3]));
 #pragma unroll S1W_SB_UNROLL
         for (int sb = 0; sb < 2; ++sb) {
             f32x4 acc[4][NT];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int joff = ((j >> 1) * S1W_R + 8 * sb) * 4;
-                const int f_k0 = fx0[j & 1], f_k1 = fx1[j & 1];
+                const int joff = 8 * sb * 4;
+                const int f_k0 = fx0[j], f_k1 = fx1[j];
                 Frag<T> b0, b1;
                 {
                     const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + f_k0 + joff);
@@ -332,24 +347,28 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     const int hrow = lane / 6, hseg = lane - hrow * 6;
     const bool hlane = lane < 60;
     const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);
-    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);
+    const unsigned st_lds = (unsigned)((s1w_rowoff(hrow) + 4 * hseg) * 4);
     const unsigned plane = (unsigned)(H * W) * 4u;
     const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
     const __amdgpu_buffer_rsrc_t drs = hyb_rsrc(a.dp, (unsigned)((long long)a.N * Ho * Wo * Cop * (int)sizeof(T)));
     const unsigned OOB = 0xFFFFFFF0u;
-    const int f_k0 = ((2 * wy + (q < 3 ? q : 0)) * S1W_R + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
-    const int f_k1 = ((2 * wy + (q == 0 ? 1 : 2)) * S1W_R + 2 * wx + 3 + 2) * 4;
+    int f_k0[2], f_k1[2];                                                      // [jy]: window rows 2 wy + jy
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+        f_k0[jy] = (s1w_rowoff(2 * wy + jy + (q < 3 ? q : 0)) + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
+        f_k1[jy] = (s1w_rowoff(2 * wy + jy + (q == 0 ? 1 : 2)) + 2 * wx + 3 + 2) * 4;
+    }
     const unsigned dp_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
     // pixels-as-K operands.  K index i of a 32-pixel step = (row i / 8, column i % 8) of 4 rows; this lane group (q) holds i = 4q .. 4q+3
     // (lo) and 16 + 4q .. (hi = two rows further down); within a 16-lane group lane (pp, qq) supplies pixel i + qq, K columns 4pp .. 4pp+3.
-    const int pix_lo = ((q >> 1) * S1W_R + 4 * (q & 1) + qq + 3) * 4;           // element offset of pixel (4q + qq) of step 0, tap (0,0)
+    const int pix_col = 4 * (q & 1) + qq + 3;                                   // image column of pixel (4q + qq), tap column 0
     int boff[3];                                                               // + tap offset of K tile kt (tap = 4 kt + pp), or the constant table
     bool bconst[3];
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
         const int tap = 4 * kt + pp;
         bconst[kt] = tap >= 9;
-        boff[kt] = tap < 9 ? pix_lo + ((tap / 3) * S1W_R + tap % 3) * 4 : (tap - 9) * 4;
+        boff[kt] = tap < 9 ? (s1w_rowoff((q >> 1) + tap / 3) + pix_col + tap % 3) * 4 : (tap - 9) * 4;
     }
     const int a_lo = (4 * q + qq) * DS + 4 * pp;                               // dz tile: pixel 4q + qq, channels 4pp .. (+ 16 c)
 
@@ -405,25 +424,25 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
 #pragma unroll
             for (int h8 = 0; h8 < NT / 2; ++h8) gcur[sb][h8] = gpf[sb][h8];
         if (more) prefetch(n_n, by_n_, bx_n_);
-        int fx0[2] = {f_k0, f_k0 + 4}, fx1[2] = {f_k1, f_k1 + 4};
-        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]));
+        int fx0[4] = {f_k0[0], f_k0[0] + 4, f_k0[1], f_k0[1] + 4}, fx1[4] = {f_k1[0], f_k1[0] + 4, f_k1[1], f_k1[1] + 4};      // [j = 2 jy + jx]
+        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]), "+v"(fx0[3]), "+v"(fx1[3]));
 #pragma unroll 1
         for (int sb = 0; sb < 2; ++sb) {
             // ---- conv of the 8x8 sub-block (as in the forward kernels)
             f32x4 acc[4][NT];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int joff = ((j >> 1) * S1W_R + 8 * sb) * 4;
+                const int joff = 8 * sb * 4;
                 Frag<T> b0, b1;
                 {
-                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx0[j & 1] + joff);
-                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx0[j & 1] + joff + 4);
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx0[j] + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx0[j] + joff + 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { b0.v[c] = lo.v[c]; b0.v[4 + c] = hi.v[c]; }
                 }
                 {
-                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx1[j & 1] + joff);
-                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx1[j & 1] + joff + 4);
+                    const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + fx1[j] + joff);
+                    const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + fx1[j] + joff + 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { b1.v[c] = lo.v[c]; b1.v[4 + c] = hi.v[c]; }
                 }
@@ -472,11 +491,11 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
                     const T* lo = dyt + ks * 32 * DS + a_lo + c * 16;
                     S1BTr<T>::read(af[c], lo, lo + 16 * DS);
                 }
-                const int pstep = (4 * ks * S1W_R + 8 * sb) * 4;                // rows 4 ks .., columns 8 sb .. of the image
+                const int pstep = (2 * ks * S1W_PAIR + 8 * sb) * 4;                // rows 4 ks .., columns 8 sb .. of the image
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const T* lo = bconst[kt] ? ctab + boff[kt] : img + boff[kt] + pstep;
-                    const T* hi = bconst[kt] ? lo : lo + 2 * S1W_R * 4;
+                    const T* hi = bconst[kt] ? lo : lo + S1W_PAIR * 4;
                     S1BTr<T>::read(bf[kt], lo, hi);
 #pragma unroll
                     for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf[kt], wacc[kt][c]);
@@ -548,18 +567,18 @@ __global__ __launch_bounds__(256) void stage1w_gram_kernel(S1Args a) {
     const int hrow = lane / 6, hseg = lane - hrow * 6;
     const bool hlane = lane < 60;
     const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);
-    const unsigned st_lds = (unsigned)((hrow * S1W_R + 4 * hseg) * 4);
+    const unsigned st_lds = (unsigned)((s1w_rowoff(hrow) + 4 * hseg) * 4);
     const unsigned plane = (unsigned)(H * W) * 4u;
     const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
     const unsigned OOB = 0xFFFFFFF0u;
-    const int pix_lo = ((q >> 1) * S1W_R + 4 * (q & 1) + qq + 3) * 4;
+    const int pix_col = 4 * (q & 1) + qq + 3;
     int boff[3];
     bool bconst[3];
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
         const int tap = 4 * kt + pp;
         bconst[kt] = tap >= 9;
-        boff[kt] = tap < 9 ? pix_lo + ((tap / 3) * S1W_R + tap % 3) * 4 : (tap - 9) * 4;
+        boff[kt] = tap < 9 ? (s1w_rowoff((q >> 1) + tap / 3) + pix_col + tap % 3) * 4 : (tap - 9) * 4;
     }
     int n_c = blk_begin / bpi, by_c, bx_c;
     { const int rem = blk_begin - n_c * bpi; by_c = rem / bx_n; bx_c = rem - by_c * bx_n; }
@@ -600,11 +619,11 @@ __global__ __launch_bounds__(256) void stage1w_gram_kernel(S1Args a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 Frag<T> bf[3];
-                const int pstep = (4 * ks * S1W_R + 8 * sb) * 4;
+                const int pstep = (2 * ks * S1W_PAIR + 8 * sb) * 4;
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const T* lo = bconst[kt] ? ctab + boff[kt] : img + boff[kt] + pstep;
-                    const T* hi = bconst[kt] ? lo : lo + 2 * S1W_R * 4;
+                    const T* hi = bconst[kt] ? lo : lo + S1W_PAIR * 4;
                     S1BTr<T>::read(bf[kt], lo, hi);
                 }
                 gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
