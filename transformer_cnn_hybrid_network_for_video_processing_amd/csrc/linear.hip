@@ -448,14 +448,13 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         int rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
         if (rc) return rc;
     }
-    if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]
+    if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]; the bias gradient (column sums of dym) rides in the same launch
         GemmArgs a{};
-        a.g[0] = GemmGroup{dym, x, dW, nullptr, nullptr, nullptr};
+        a.g[0] = GemmGroup{dym, x, dW, nullptr, nullptr, db};
         a.Mo = N; a.No = K; a.R = M; a.lda = N; a.ldb = ldx; a.ldc = K; a.relu = 0; a.accumulate = 0;
         int rc = launch_gemm<T, T, T, float, true, true>(a, 1, st);
         if (rc) return rc;
-    }
-    if (db) {
+    } else if (db) {
         hipLaunchKernelGGL(colsum_kernel<T>, dim3(hyb_cdiv(N, 32)), dim3(256), 0, st, dym, db, M, N);
         HYB_LAUNCH_CHECK();
     }
