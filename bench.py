@@ -345,10 +345,35 @@ def main():
     x = torch.rand(args.batch, args.frames, 3, args.size, args.size, generator=g).to(dev)
     y = torch.randint(0, CFG["num_classes"], (args.batch,), generator=g).to(dev)
 
+    graph_fallback = None
     if graphed:
         # the whole step captured once as three hipGraphs (forward + temporal backward | backbone backward | AdamW); the gradient
-        # all-reduce runs between them, outside the graphs, overlapped with the backbone backward (graph.py)
-        trainer = P.GraphedTrainStep(model, crit, opt, x, y)
+        # all-reduce runs between them, outside the graphs, overlapped with the backbone backward (graph.py).  If capture fails on
+        # ANY rank (it has only ever run on one-GPU boxes), every rank falls back to the eager step -- same kernels, same arithmetic --
+        # and the JSON line says so, rather than losing the measurement.
+        trainer = None
+        try:
+            if os.environ.get("HYB_BENCH_FORCE_GRAPH_FAIL"):                # test hook for the fallback path (tests/test_gpu_dp.py)
+                raise RuntimeError("forced by HYB_BENCH_FORCE_GRAPH_FAIL")
+            trainer = P.GraphedTrainStep(model, crit, opt, x, y)
+        except Exception as e:                                             # noqa: BLE001 (reported in the output line)
+            graph_fallback = f"{type(e).__name__}: {e}"[:300]
+        if world > 1:
+            ok = torch.tensor([0 if graph_fallback else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and graph_fallback is None:
+                graph_fallback = "graph capture failed on another rank"
+        if graph_fallback is not None:
+            if trainer is not None:
+                trainer.close()
+            from transformer_cnn_hybrid_network_for_video_processing_amd import ops as _ops
+            _ops.set_step_counter(None)
+            opt.set_step_counter(None)
+            for p_ in model.parameters():
+                p_.grad = None
+            trainer, graphed = None, False
+            reducer = GradAllReducer(model) if world > 1 else None
+    if graphed:
         step, fwd_bwd = trainer.step, trainer.fwd_bwd
     else:
         def step():
@@ -453,7 +478,7 @@ def main():
                                    f"CNN 32-64-128-256 + 2-layer transformer d={args.d_model} h={args.heads} hid={args.hidden}, 8 classes",
                        "global_batch": args.batch * world, "frames": args.frames,
                        "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw",
-                       "launch": "3 replayed hipGraphs per step (graph.GraphedTrainStep)" if graphed else "eager (one Python-issued launch per kernel)",
+                       "launch": "3 replayed hipGraphs per step (graph.GraphedTrainStep)" if graphed else "eager (one Python-issued launch per kernel)" + (f"; graph capture fell back: {graph_fallback}" if graph_fallback else ""),
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",

@@ -39,6 +39,19 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     assert d["final_loss"] == d["final_loss"]                                                  # finite
 
 
+def test_bench_falls_back_to_eager_on_every_rank_when_graph_capture_fails():
+    """The replayed-graph step has only ever been captured on one-GPU boxes: if capture raises on any rank, all ranks take the eager step
+    (decided by an all-reduce of the outcome) and the JSON line says so."""
+    env = dict(os.environ, HYB_DIST_BACKEND="gloo", HYB_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", HYB_BENCH_FORCE_GRAPH_FAIL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "2", "--frames", "4", "--size", "64", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "fell back" in d["config"]["launch"] and "forced" in d["config"]["launch"]
+
+
 def test_bench_plain_form_launches_its_own_ranks():
     """VERDICT r1 / ADVICE r1: `python bench.py --gpus 2` (no launcher: the form the driver runs) must start 2 ranks itself
     and report n_gpus == 2 -- it used to run one GPU silently."""
