@@ -23,7 +23,7 @@ for k in sorted(fe, key=lambda k: -sum(fe[k])):
     f_avg = sum(fe[k]) / len(fe[k]); w_avg = sum(wr.get(k, [0])) / max(1, len(wr.get(k, [0])))
     fb, wb = f_avg * 1024 * 2, w_avg * 1024
     rows.append((short(k), len(fe[k]), round(f_avg), round(fb), round(w_avg), round(fb + wb)))
-    m = re.search(r"wgrad_v2_kernel<(true|false), (\d+)>", k) if ("wgrad" in k and "reduce" not in k) else None
+    m = re.search(r"wgrad_v2_kernel<(true|false), (\d+)[,>]", k) if ("wgrad" in k and "reduce" not in k) else None
     name = "wgrad_v2_kernel<%s, %s>" % (m.group(1), m.group(2)) if m else short(k)
     if name not in traffic:
         traffic[name] = {"hbm_bytes_per_launch": fb + wb, "fetch_size_kb_raw_avg": f_avg, "write_size_kb_avg": w_avg, "launches_sampled": len(fe[k]),
