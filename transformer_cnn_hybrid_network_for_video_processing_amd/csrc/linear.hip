@@ -152,13 +152,35 @@ struct DwGroup {
     int N, K, lddy, ldx;       // dW is [N][K]; dy rows have lddy elements, x rows ldx
     int tiles_x, tile_begin;
 };
-struct DwArgs { DwGroup g[6]; int ngroups, M; };
+struct DwArgs {
+    DwGroup g[6]; int ngroups, M;
+    // optional rider (the encoder backward's LayerNorm-affine gradients): blocks past `tiles` sum ln_rows partial rows of 2*ln_D floats
+    int tiles; const float* ln_part; int ln_rows, ln_D; float* ln_dgamma; float* ln_dbeta;
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
     constexpr int BM = 64, WM = 32, MT = 2;
     __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
     __shared__ __attribute__((aligned(16))) T Bs[BM * LDS_ROW];
+    if ((int)blockIdx.x >= args.tiles) {                   // rider: column c of the LayerNorm partial rows, fixed order, eight loads in flight
+        const int c = ((int)blockIdx.x - args.tiles) * 256 + (int)threadIdx.x;
+        if (c >= 2 * args.ln_D) return;
+        const float* col = args.ln_part + c;
+        const long long ld = 2LL * args.ln_D;
+        float s = 0.f;
+        int r = 0;
+        for (; r + 8 <= args.ln_rows; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = col[(long long)(r + j) * ld];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < args.ln_rows; ++r) s += col[(long long)r * ld];
+        if (c < args.ln_D) args.ln_dgamma[c] = s; else args.ln_dbeta[c - args.ln_D] = s;
+        return;
+    }
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < 6; ++i)
@@ -506,7 +528,8 @@ int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const vo
 
 // Internal: weight + bias gradients of up to 6 Linear layers of different shapes in one launch (see gemm_dw_multi_kernel).
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
-                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st) {
+                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
+                        const float* ln_part, int ln_rows, int ln_D, float* ln_dgamma, float* ln_dbeta) {
     if (groups < 1 || groups > 6 || M < 1) return HYB_E_ARG;
     DwArgs a{};
     int tiles = 0;
@@ -516,9 +539,14 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
         a.g[i] = DwGroup{dy[i], mask ? mask[i] : nullptr, x[i], dW[i], db ? db[i] : nullptr, N[i], K[i], lddy[i], ldx[i], tx, tiles};
         tiles += tx * ty;
     }
-    a.ngroups = groups; a.M = M;
-    if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(tiles), dim3(256), 0, st, a);
-    else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(tiles), dim3(256), 0, st, a);
+    a.ngroups = groups; a.M = M; a.tiles = tiles;
+    int blocks = tiles;
+    if (ln_part && ln_rows > 0 && ln_D > 0 && ln_dgamma && ln_dbeta) {
+        a.ln_part = ln_part; a.ln_rows = ln_rows; a.ln_D = ln_D; a.ln_dgamma = ln_dgamma; a.ln_dbeta = ln_dbeta;
+        blocks += hyb_cdiv(2 * ln_D, 256);
+    }
+    if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, st, a);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;

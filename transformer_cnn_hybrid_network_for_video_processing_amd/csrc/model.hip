@@ -19,7 +19,8 @@ int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const fl
                             void* stream);
 int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
-                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st);
+                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
+                        const float* ln_part = nullptr, int ln_rows = 0, int ln_D = 0, float* ln_dgamma = nullptr, float* ln_dbeta = nullptr);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
@@ -338,9 +339,8 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
             HYB_HIP_TRY(hipStreamWaitEvent(side->s, side->fork, 0));
             ws_st = side->s;
         }
-        // the layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients, fixed order
-        HYB_TRY(hyb_ln_rows_reduce(b.lnpart, 2 * lnrows, D, G[12], G[13], ws_st));
-        // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches)
+        // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches); the
+        // layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients ride in the same launch
         {
             const char* dq_ = (const char*)b.dqkv; const char* qk_ = base + lay.qkv;
             const void* dy_[6] = {b.g1, b.dh, b.g1b, dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
@@ -350,7 +350,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
             float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
             const int N_[6] = {D, Hid, D, D, D, D}, K_[6] = {Hid, D, D, D, D, D};
             const int lddy_[6] = {D, Hid, D, 3 * D, 3 * D, 3 * D}, ldx_[6] = {Hid, D, D, D, D, D};
-            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, ws_st));
+            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, ws_st, b.lnpart, 2 * lnrows, D, G[12], G[13]));
         }
         if (side) { HYB_HIP_TRY(hipEventRecord(side->done[i & 1], side->s)); pending[i & 1] = true; }
         gA = gx;
