@@ -215,10 +215,23 @@ __global__ void head_bwd_dx_kernel(const float* __restrict__ W, const float* __r
 // dW[c][d] = sum_b dlogits[b][c] * mean_s x[b][s][d];  db[c] = sum_b dlogits[b][c]
 // grid (D/64, C-chunks of 16), 256 threads = 64 features x 4 clip groups (clips b = group, group + 4, ...); the groups are
 // combined through LDS in a fixed order
+// (with dx_rider: the blocks y >= ceil(C/16) of the same launch form dx, the head's input gradient -- one launch for the whole head backward)
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, float* __restrict__ dW,
-                                                          float* __restrict__ db, int B, int S, int D, int C) {
+                                                          float* __restrict__ db, int B, int S, int D, int C, const float* __restrict__ W,
+                                                          T* __restrict__ dx_rider, int yblocks) {
     __shared__ float red[4][16][64];
+    if ((int)blockIdx.y >= yblocks) {                      // dx[b][s][d] = (1/S) sum_c dlogits[b][c] W[c][d] for this block's 64 features
+        const int d = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (d >= D) return;
+        for (int b = ((int)blockIdx.y - yblocks) * 4 + (threadIdx.x >> 6); b < B; b += 4 * ((int)gridDim.y - yblocks)) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += dlogits[b * C + c] * W[(long long)c * D + d];
+            const T v = from_f32<T>(s / (float)S);
+            for (int t = 0; t < S; ++t) dx_rider[((long long)b * S + t) * D + d] = v;
+        }
+        return;
+    }
     const int dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + dl;
     const int c0 = blockIdx.y * 16;
@@ -363,14 +376,15 @@ extern "C" int hyb_head_bwd(int dtype, const void* x, const float* W, const floa
     HYB_CHECK_ARG(x && W && dlogits && B > 0 && S > 0 && D > 0 && C > 0 && C <= 64);
     hipStream_t st = (hipStream_t)stream;
     if (dtype != HYB_F32 && dtype != HYB_BF16) return HYB_E_ARG;
-    if (dx) {
+    if (dx && !dW) {
         if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dx_kernel<float>, dim3(B), dim3(256), 0, st, W, dlogits, (float*)dx, S, D, C);
         else hipLaunchKernelGGL(head_bwd_dx_kernel<bf16>, dim3(B), dim3(256), 0, st, W, dlogits, (bf16*)dx, S, D, C);
         HYB_LAUNCH_CHECK();
     }
-    if (dW) {
-        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(256), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C);
-        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 64), hyb_cdiv(C, 16)), dim3(256), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C);
+    if (dW) {        // one launch: weight/bias gradient blocks, and (when asked) the input-gradient blocks riding behind them
+        const int yb = hyb_cdiv(C, 16), xb = dx ? hyb_cdiv(B, 4) : 0;
+        if (dtype == HYB_F32) hipLaunchKernelGGL(head_bwd_dw_kernel<float>, dim3(hyb_cdiv(D, 64), yb + xb), dim3(256), 0, st, (const float*)x, dlogits, dW, db, B, S, D, C, W, (float*)dx, yb);
+        else hipLaunchKernelGGL(head_bwd_dw_kernel<bf16>, dim3(hyb_cdiv(D, 64), yb + xb), dim3(256), 0, st, (const bf16*)x, dlogits, dW, db, B, S, D, C, W, (bf16*)dx, yb);
         HYB_LAUNCH_CHECK();
     }
     return 0;
