@@ -355,6 +355,38 @@ int hyb_fct_dropout(const float* x, float* y, long long n, float p, unsigned lon
  * dataset.pyc src L106-113): frames cross PCIe as bytes and become the fp32 NCHW clip tensor the first conv stage reads. */
 int hyb_frames_u8hwc_to_f32chw(const unsigned char* src, float* dst, long long frames, int H, int W, int C, void* stream);
 
+/* ---- ResNet-bottleneck backbone `Encoder_32K` (only bytecode of it ships with the reference:
+ * __pycache__/AE_256_32K.cpython-38.pyc, read as data -- `Bottleneck` src L21-53, `Encoder_32K` src L58-137).  NHWC fp32 with the
+ * true channel counts, exact-fp32 arithmetic like the FCT entry points above, which these generalise.
+ *
+ * nn.Conv2d(Ci, Co, k, stride, padding, dilation, bias) forward / backward: the stem Conv2d(3, 64, 7, 2, 3, bias=False) (src L62),
+ * the bottleneck's 1x1 / 3x3-stride-s / 1x1 (src L25-30), the down-sampling Conv2d(.., 1, stride, bias=False) (src L99-102) and the
+ * tail's Conv2d(.., 3, 1, 1) with bias (src L70-88).  x [N,H,W,Ci], w [Co,Ci,k,k], y [N,Ho,Wo,Co] with torch's output size
+ * floor((H + 2 pad - dilation (k-1) - 1) / stride) + 1; act / z_out / saved as for hyb_fct_conv_*, which are these at k=3, stride 1. */
+size_t hyb_conv2d_workspace(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dilation);
+int hyb_conv2d_fwd(const float* x, const float* w, const float* b /* or NULL */, float* y, float* z_out /* or NULL */, int N, int H, int W, int Ci,
+                   int Co, int k, int stride, int pad, int dilation, int act, void* workspace, size_t workspace_bytes, void* stream);
+size_t hyb_conv2d_bwd_workspace(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dilation);
+int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, const float* saved, float* dx /* or NULL */, float* dw, float* db /* or NULL */,
+                   int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dilation, int act, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* nn.BatchNorm2d over P = N*H*W pixel rows of C channels (C % 4 == 0, C/4 a divisor of 256), optionally fused with the bottleneck's
+ * `out += residual` and nn.ReLU (src L44-52): y = relu?( (x - mean) / sqrt(var + eps) * gamma + beta (+ residual) ).
+ * training != 0: batch statistics (biased variance), running_mean / running_var (or NULL) updated in place with `momentum` and the
+ * unbiased variance, like torch; training == 0: the running statistics normalise.  coef [4][C] (a, b, mean, invstd) is written by
+ * the forward and read by the backward; y in the backward is the forward's output (ReLU mask; ignored when relu == 0). */
+size_t hyb_bn2d_workspace(long long P, int C);
+int hyb_bn2d_fwd(const float* x, const float* gamma, const float* beta, const float* residual /* or NULL */, float* y, float* coef,
+                 float* running_mean, float* running_var, long long P, int C, float eps, float momentum, int training, int relu,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int hyb_bn2d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* coef, float* dx,
+                 float* dresidual /* or NULL */, float* dgamma, float* dbeta, long long P, int C, int training, int relu, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* nn.Dropout2d(p) in train mode (src L92, L113, L136) on [N,H,W,C]: one decision per (image, channel) plane from the counter-based RNG
+ * keyed by (seed + *seed_inc); the backward is the same call on the gradient. */
+int hyb_dropout2d(const float* x, float* y, int N, long long HW, int C, float p, unsigned long long seed, const unsigned long long* seed_inc,
+                  void* stream);
+
 /* ---- optimizer step: torch.optim.AdamW of Model.py:153 / FCT.py:305, all tensors in one launch ---------
  * Same update as torch.optim.AdamW(betas=(beta1,beta2), eps, weight_decay, amsgrad=False, maximize=False) at step number
  * `step` (1-based).  params/grads/exp_avg/exp_avg_sq: HOST arrays of `count` device pointers (fp32 tensors of numel[i]

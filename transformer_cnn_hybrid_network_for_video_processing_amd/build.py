@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhybrid_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "side.hip", "fct.hip", "fct_bwd.hip", "optim.hip"]
+SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "side.hip", "fct.hip", "fct_bwd.hip", "bn2d.hip", "optim.hip"]
 
 
 # Per-file compiler flags.  conv_first_wave.hip: MFMA results in VGPRs instead of AGPRs -- its kernels are bound by VALU instruction issue

@@ -13,6 +13,7 @@
 //   DiceLoss                                                   Metrics.py:5-22
 #include <math.h>
 #include "hyb_common.h"
+#include "conv_geo.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
@@ -24,33 +25,6 @@ namespace {
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int up8(int v) { return (v + 7) / 8 * 8; }
 #define FCT_TRY(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
-
-// w [Co][Ci][3][3] -> wp [Co][Kp], k = tap * Ci + ci, zero padded to Kp
-__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Kp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Co * Kp) return;
-    const int co = i / Kp, k = i - co * Kp;
-    float v = 0.f;
-    if (k < 9 * Ci) { const int tap = k / Ci, ci = k - tap * Ci; v = w[((long long)co * Ci + ci) * 9 + tap]; }
-    wp[i] = v;
-}
-
-// col [P][Kp] <- x NHWC; k = tap * Ci + ci reads pixel (h + (tap/3 - 1) d, w + (tap%3 - 1) d); zero outside the image and for k >= 9 Ci
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long long P, int H, int W, int Ci,
-                                                     int Kp, int dil) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P * Kp) return;
-    const long long pix = i / Kp;
-    const int k = (int)(i - pix * Kp);
-    float v = 0.f;
-    if (k < 9 * Ci) {
-        const int tap = k / Ci, ci = k - tap * Ci;
-        const int w0 = (int)(pix % W), h0 = (int)((pix / W) % H);
-        const int hh = h0 + (tap / 3 - 1) * dil, ww = w0 + (tap % 3 - 1) * dil;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = x[(pix + (long long)(hh - h0) * W + (ww - w0)) * Ci + ci];
-    }
-    col[i] = v;
-}
 
 __device__ __forceinline__ float gelu_erf(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }      // nn.GELU() default (erf form)
 
@@ -227,44 +201,55 @@ constexpr long long CONV_CHUNK_BYTES = 512ll << 20;     // im2col rows are produ
 
 }  // namespace
 
-extern "C" size_t hyb_fct_conv_workspace(int N, int H, int W, int Ci, int Co) {
-    if (N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return 0;
-    const int Kp = up8(9 * Ci);
-    const long long per_img = (long long)H * W * Kp * 4;
+// ---- general Conv2d forward (conv_geo.h): patch matrix in image chunks + exact-fp32 MFMA GEMM with bias / ReLU epilogue -------------
+extern "C" size_t hyb_conv2d_workspace(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dilation) {
+    ConvGeo g;
+    if (N < 1 || Co < 1 || !conv_geo_make(g, H, W, Ci, k, stride, pad, dilation)) return 0;
+    const long long per_img = (long long)g.Ho * g.Wo * g.Kp * 4;
     long long nb = CONV_CHUNK_BYTES / per_img; if (nb < 1) nb = 1; if (nb > N) nb = N;
-    return al256((size_t)Co * Kp * 4) + al256((size_t)nb * per_img);
+    return al256((size_t)Co * g.Kp * 4) + (conv_geo_identity(g) ? 0 : al256((size_t)nb * per_img));
 }
 
-extern "C" int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, float* z_out, int N, int H, int W, int Ci, int Co,
-                                int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
-    HYB_CHECK_ARG(x && w && y && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && dilation >= 1 && dilation <= 8);
+extern "C" int hyb_conv2d_fwd(const float* x, const float* w, const float* b, float* y, float* z_out, int N, int H, int W, int Ci, int Co, int k,
+                              int stride, int pad, int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    ConvGeo g;
+    HYB_CHECK_ARG(x && w && y && workspace && N > 0 && Co > 0 && conv_geo_make(g, H, W, Ci, k, stride, pad, dilation));
     HYB_CHECK_ARG(act >= HYB_ACT_NONE && act <= HYB_ACT_SIGMOID);
-    if (workspace_bytes < hyb_fct_conv_workspace(N, H, W, Ci, Co)) return HYB_E_WORKSPACE;
+    if (workspace_bytes < hyb_conv2d_workspace(N, H, W, Ci, Co, k, stride, pad, dilation)) return HYB_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int Kp = up8(9 * Ci);
+    const int Kp = g.Kp;
+    const bool ident = conv_geo_identity(g);
     float* wp = (float*)workspace;
     float* col = (float*)((char*)workspace + al256((size_t)Co * Kp * 4));
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid1((long long)Co * Kp)), dim3(256), 0, st, w, wp, Co, Ci, Kp);
+    hipLaunchKernelGGL(conv_pack_g_kernel, dim3(grid1((long long)Co * Kp)), dim3(256), 0, st, w, wp, Co, Ci, k * k, Kp);
     HYB_LAUNCH_CHECK();
-    const long long per_img = (long long)H * W * Kp * 4;
+    const long long per_img = (long long)g.Ho * g.Wo * Kp * 4;
     long long nb = CONV_CHUNK_BYTES / per_img; if (nb < 1) nb = 1; if (nb > N) nb = N;
     for (int n0 = 0; n0 < N; n0 += (int)nb) {
         const int nn = N - n0 < nb ? N - n0 : (int)nb;
-        const long long P = (long long)nn * H * W;
-        if (P > 0x7fffffff / 32 * 32) return HYB_E_ARG;
-        hipLaunchKernelGGL(im2col_kernel, dim3(grid1(P * Kp)), dim3(256), 0, st, x + (long long)n0 * H * W * Ci, col, P, H, W, Ci, Kp, dilation);
-        HYB_LAUNCH_CHECK();
+        const long long P = (long long)nn * g.Ho * g.Wo, off = (long long)n0 * g.Ho * g.Wo;
+        if (P > 0x7fffffff / 32 * 32 || (long long)nn * H * W > 0x7fffffff / 32 * 32) return HYB_E_ARG;
+        const float* xin = x + (long long)n0 * H * W * Ci;
+        if (!ident) { launch_im2col(xin, col, P, g, st); HYB_LAUNCH_CHECK(); }
         // GELU / sigmoid: the GEMM leaves the pre-activation (in z_out when the caller keeps it for backward, else in y)
         float* gemm_out = ((act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) && z_out) ? z_out : y;
-        const void* A[1] = {col}; const void* B[1] = {wp}; void* Cc[1] = {gemm_out + (long long)n0 * H * W * Co}; const float* bias[1] = {b};
+        const void* A[1] = {ident ? xin : col}; const void* B[1] = {wp}; void* Cc[1] = {gemm_out + off * Co}; const float* bias[1] = {b};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, bias, 0, (int)P, Co, Kp, Kp, Kp, Co, act == HYB_ACT_RELU, 0, st));
     }
     if (act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) {
-        const long long n = (long long)N * H * W * Co;
+        const long long n = (long long)N * g.Ho * g.Wo * Co;
         hipLaunchKernelGGL(act_kernel, dim3(grid1(n)), dim3(256), 0, st, z_out ? (const float*)z_out : (const float*)y, y, n, act);
         HYB_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// FCT's nn.Conv2d(.., 3, 1, padding="same"[, dilation=d]) is the general convolution at k = 3, stride 1, pad = d
+extern "C" size_t hyb_fct_conv_workspace(int N, int H, int W, int Ci, int Co) { return hyb_conv2d_workspace(N, H, W, Ci, Co, 3, 1, 1, 1); }
+extern "C" int hyb_fct_conv_fwd(const float* x, const float* w, const float* b, float* y, float* z_out, int N, int H, int W, int Ci, int Co,
+                                int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(dilation >= 1 && dilation <= 8);
+    return hyb_conv2d_fwd(x, w, b, y, z_out, N, H, W, Ci, Co, 3, 1, dilation, dilation, act, workspace, workspace_bytes, stream);
 }
 
 template <typename F>

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "hyb_common.h"
+#include "conv_geo.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
@@ -48,47 +49,14 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     dz[i] = v;
 }
 
-// wpt [Kp][Co8] <- w [Co][Ci][3][3] (k = tap*Ci + ci), zero padded
-__global__ void conv_pack_t_kernel(const float* __restrict__ w, float* __restrict__ wpt, int Co, int Ci, int Kp, int Co8) {
+// wpt [Kp][Co8] <- w [Co][Ci][k][k] (column = tap*Ci + ci, kk = k*k taps), zero padded
+__global__ void conv_pack_t_kernel(const float* __restrict__ w, float* __restrict__ wpt, int Co, int Ci, int kk, int Kp, int Co8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Kp * Co8) return;
     const int k = i / Co8, co = i - k * Co8;
     float v = 0.f;
-    if (k < 9 * Ci && co < Co) { const int tap = k / Ci, ci = k - tap * Ci; v = w[((long long)co * Ci + ci) * 9 + tap]; }
+    if (k < kk * Ci && co < Co) { const int tap = k / Ci, ci = k - tap * Ci; v = w[((long long)co * Ci + ci) * kk + tap]; }
     wpt[i] = v;
-}
-
-__global__ __launch_bounds__(256) void im2col_b_kernel(const float* __restrict__ x, float* __restrict__ col, long long P, int H, int W, int Ci,
-                                                       int Kp, int dil) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P * Kp) return;
-    const long long pix = i / Kp;
-    const int k = (int)(i - pix * Kp);
-    float v = 0.f;
-    if (k < 9 * Ci) {
-        const int tap = k / Ci, ci = k - tap * Ci;
-        const int w0 = (int)(pix % W), h0 = (int)((pix / W) % H);
-        const int hh = h0 + (tap / 3 - 1) * dil, ww = w0 + (tap % 3 - 1) * dil;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = x[(pix + (long long)(hh - h0) * W + (ww - w0)) * Ci + ci];
-    }
-    col[i] = v;
-}
-
-// dx[p][ci] = sum_tap dcol[p - delta_tap][tap*Ci + ci]  (the pixel q = p - delta_tap read x at p through tap `tap`)
-__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, long long P, int H, int W, int Ci,
-                                                     int Kp, int dil) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P * Ci) return;
-    const long long pix = i / Ci;
-    const int ci = (int)(i - pix * Ci);
-    const int w0 = (int)(pix % W), h0 = (int)((pix / W) % H);
-    float s = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int hh = h0 - (tap / 3 - 1) * dil, ww = w0 - (tap % 3 - 1) * dil;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) s += dcol[(pix + (long long)(hh - h0) * W + (ww - w0)) * Kp + tap * Ci + ci];
-    }
-    dx[i] = s;
 }
 
 // ---- generic sliced weight gradient:  part[slice][n][k] = sum_{p in slice} dy[p][n] * x[p][k]   (n < Nn, k < K; 64 x 64 tiles) -------
@@ -284,11 +252,11 @@ __global__ __launch_bounds__(256) void colsum_slice_kernel(const float* __restri
         __syncthreads();
     }
 }
-// dw [Co][Ci][3][3] <- dWp [Co8 or Co][Kp]
-__global__ void conv_unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int Kp) {
+// dw [Co][Ci][k][k] <- dWp [Co8 or Co][Kp]
+__global__ void conv_unpack_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int kk, int Kp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Co * Ci * 9) return;
-    const int tap = i % 9, ci = (i / 9) % Ci, co = i / (9 * Ci);
+    if (i >= Co * Ci * kk) return;
+    const int tap = i % kk, ci = (i / kk) % Ci, co = i / (kk * Ci);
     dw[i] = dwp[(long long)co * Kp + tap * Ci + ci];
 }
 
@@ -620,55 +588,70 @@ int hyb_sliced_colsum(const float* v, int ldv, float* out, long long P, int C, i
     return 0;
 }
 
-extern "C" size_t hyb_fct_conv_bwd_workspace(int N, int H, int W, int Ci, int Co) {
-    if (N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return 0;
-    const int Kp = up8(9 * Ci), Co8 = up8(Co);
-    const long long per_img = (long long)H * W * (Kp + Co8) * 4;
+// ---- general Conv2d backward (conv_geo.h) ----------------------------------------------------------------------------------------
+extern "C" size_t hyb_conv2d_bwd_workspace(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dilation) {
+    ConvGeo g;
+    if (N < 1 || Co < 1 || !conv_geo_make(g, H, W, Ci, k, stride, pad, dilation)) return 0;
+    const int Kp = g.Kp, Co8 = up8(Co);
+    const long long per_img = (long long)g.Ho * g.Wo * (Kp + Co8) * 4;
     long long nb = CHUNK_BYTES / per_img; if (nb < 1) nb = 1; if (nb > N) nb = N;
-    const long long Pc = nb * H * W;
-    return al256((size_t)Kp * Co8 * 4) + al256((size_t)Pc * Co8 * 4) + al256((size_t)Pc * Kp * 4) + al256((size_t)Co8 * Kp * 4) + al256((size_t)Co8 * 4) +
-           hyb_sliced_wgrad_workspace(Pc, Co8, Kp) + hyb_sliced_colsum_workspace(Pc, Co8);
+    const long long Pc = nb * g.Ho * g.Wo;
+    return al256((size_t)Kp * Co8 * 4) + al256((size_t)Pc * Co8 * 4) + (conv_geo_identity(g) ? 0 : al256((size_t)Pc * Kp * 4)) +
+           al256((size_t)Co8 * Kp * 4) + al256((size_t)Co8 * 4) + hyb_sliced_wgrad_workspace(Pc, Co8, Kp) + hyb_sliced_colsum_workspace(Pc, Co8);
 }
 
-extern "C" int hyb_fct_conv_bwd(const float* dy, const float* x, const float* w, const float* saved, float* dx, float* dw, float* db, int N, int H,
-                                int W, int Ci, int Co, int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
-    HYB_CHECK_ARG(dy && x && w && dw && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && dilation >= 1 && dilation <= 8);
-    HYB_CHECK_ARG(act == HYB_ACT_NONE || saved);
-    if (workspace_bytes < hyb_fct_conv_bwd_workspace(N, H, W, Ci, Co)) return HYB_E_WORKSPACE;
+extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, const float* saved, float* dx, float* dw, float* db, int N, int H,
+                              int W, int Ci, int Co, int k, int stride, int pad, int dilation, int act, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    ConvGeo g;
+    HYB_CHECK_ARG(dy && x && w && dw && workspace && N > 0 && Co > 0 && conv_geo_make(g, H, W, Ci, k, stride, pad, dilation));
+    HYB_CHECK_ARG(act >= HYB_ACT_NONE && act <= HYB_ACT_SIGMOID && (act == HYB_ACT_NONE || saved));
+    if (workspace_bytes < hyb_conv2d_bwd_workspace(N, H, W, Ci, Co, k, stride, pad, dilation)) return HYB_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int Kp = up8(9 * Ci), Co8 = up8(Co);
-    const long long per_img = (long long)H * W * (Kp + Co8) * 4;
+    const int Kp = g.Kp, Co8 = up8(Co), kk = k * k;
+    const bool ident = conv_geo_identity(g);
+    const bool dz_is_dy = act == HYB_ACT_NONE && Co8 == Co;          // nothing to mask or pad: the GEMMs read dy in place
+    const long long per_img = (long long)g.Ho * g.Wo * (Kp + Co8) * 4;
     long long nb = CHUNK_BYTES / per_img; if (nb < 1) nb = 1; if (nb > N) nb = N;
-    const long long Pc = nb * H * W;
+    const long long Pc = nb * g.Ho * g.Wo;
     char* ws = (char*)workspace;
     float* wpt = (float*)ws;   ws += al256((size_t)Kp * Co8 * 4);
-    float* dz = (float*)ws;    ws += al256((size_t)Pc * Co8 * 4);
-    float* col = (float*)ws;   ws += al256((size_t)Pc * Kp * 4);
+    float* dzb = (float*)ws;   ws += al256((size_t)Pc * Co8 * 4);
+    float* col = (float*)ws;   ws += ident ? 0 : al256((size_t)Pc * Kp * 4);
     float* dwp = (float*)ws;   ws += al256((size_t)Co8 * Kp * 4);
     float* dbp = (float*)ws;   ws += al256((size_t)Co8 * 4);
     void* ws_w = ws;           ws += hyb_sliced_wgrad_workspace(Pc, Co8, Kp);
     void* ws_c = ws;
-    if (dx) { hipLaunchKernelGGL(conv_pack_t_kernel, dim3(grid1((long long)Kp * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, Kp, Co8); HYB_LAUNCH_CHECK(); }
+    if (dx) { hipLaunchKernelGGL(conv_pack_t_kernel, dim3(grid1((long long)Kp * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, kk, Kp, Co8); HYB_LAUNCH_CHECK(); }
     for (int n0 = 0, chunk = 0; n0 < N; n0 += (int)nb, ++chunk) {
         const int nn = N - n0 < nb ? N - n0 : (int)nb;
-        const long long P = (long long)nn * H * W, off = (long long)n0 * H * W;
-        if (P > 0x7fffffff / 32 * 32) return HYB_E_ARG;
-        hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1(P * Co8)), dim3(256), 0, st, dy + off * Co, saved ? saved + off * Co : nullptr, dz, P, Co, Co8, act);
-        HYB_LAUNCH_CHECK();
-        if (dx) {
-            const void* A[1] = {dz}; const void* B[1] = {wpt}; void* Cc[1] = {col};
-            FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, nullptr, 0, (int)P, Kp, Co8, Co8, Co8, Kp, 0, 0, st));
-            hipLaunchKernelGGL(col2im_kernel, dim3(grid1(P * Ci)), dim3(256), 0, st, (const float*)col, dx + off * Ci, P, H, W, Ci, Kp, dilation);
+        const long long P = (long long)nn * g.Ho * g.Wo, off = (long long)n0 * g.Ho * g.Wo;
+        const long long Pin = (long long)nn * H * W, off_in = (long long)n0 * H * W;
+        if (P > 0x7fffffff / 32 * 32 || Pin > 0x7fffffff / 32 * 32) return HYB_E_ARG;
+        const float* dz = dz_is_dy ? dy + off * Co : dzb;
+        if (!dz_is_dy) {
+            hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1(P * Co8)), dim3(256), 0, st, dy + off * Co, saved ? saved + off * Co : nullptr, dzb, P, Co, Co8, act);
             HYB_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(im2col_b_kernel, dim3(grid1(P * Kp)), dim3(256), 0, st, x + off * Ci, col, P, H, W, Ci, Kp, dilation);
-        HYB_LAUNCH_CHECK();
-        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, col, Kp, dwp, db ? dbp : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
+        if (dx) {
+            const void* A[1] = {dz}; const void* B[1] = {wpt}; void* Cc[1] = {ident ? dx + off_in * Ci : col};
+            FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, nullptr, 0, (int)P, Kp, Co8, Co8, Co8, Kp, 0, 0, st));
+            if (!ident) { launch_col2im(col, dx + off_in * Ci, Pin, g, st); HYB_LAUNCH_CHECK(); }
+        }
+        if (!ident) { launch_im2col(x + off_in * Ci, col, P, g, st); HYB_LAUNCH_CHECK(); }
+        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, ident ? x + off_in * Ci : col, Kp, dwp, db ? dbp : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
     }
-    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * 9)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, Kp);
+    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * kk)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, kk, Kp);
     if (db) { hipError_t e = hipMemcpyAsync(db, dbp, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
     HYB_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" size_t hyb_fct_conv_bwd_workspace(int N, int H, int W, int Ci, int Co) { return hyb_conv2d_bwd_workspace(N, H, W, Ci, Co, 3, 1, 1, 1); }
+extern "C" int hyb_fct_conv_bwd(const float* dy, const float* x, const float* w, const float* saved, float* dx, float* dw, float* db, int N, int H,
+                                int W, int Ci, int Co, int dilation, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(dilation >= 1 && dilation <= 8);
+    return hyb_conv2d_bwd(dy, x, w, saved, dx, dw, db, N, H, W, Ci, Co, 3, 1, dilation, dilation, act, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t hyb_fct_ln_bwd_workspace(long long P, int C) {

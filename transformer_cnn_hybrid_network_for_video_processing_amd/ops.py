@@ -1510,6 +1510,190 @@ class _DiceFn(torch.autograd.Function):
         return torch.ops.hybrid.dice_loss_bwd(dloss, pred, true, ctx.smooth), None, None
 
 
+# ---------------------------------------------------------------------------------------------
+# ResNet-bottleneck backbone `Encoder_32K`: general Conv2d, BatchNorm2d (+ residual + ReLU), Dropout2d.  NHWC fp32.
+# ---------------------------------------------------------------------------------------------
+def _conv_out(n, k, stride, pad, dilation):
+    return (n + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+
+
+def conv2d_op(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, padding: int, dilation: int, act: int) -> Tuple[Tensor, Tensor]:
+    """nn.Conv2d(Ci, Co, k, stride, padding, dilation) on NHWC x, weight [Co,Ci,k,k] -> (y [N,Ho,Wo,Co], z): z is the pre-activation,
+    kept only for GELU."""
+    _require_cuda(x, weight)
+    x = _f32c(x)
+    N, H, W, Ci = x.shape
+    Co, Ci_w, k, k2 = weight.shape
+    if Ci_w != Ci or k != k2:
+        raise RuntimeError(f"conv2d: weight {tuple(weight.shape)} does not match input channels {Ci} (square kernels only)")
+    Ho, Wo = _conv_out(H, k, stride, padding, dilation), _conv_out(W, k, stride, padding, dilation)
+    if Ho < 1 or Wo < 1:
+        raise RuntimeError(f"conv2d: kernel {k} (dilation {dilation}) larger than the padded input {H}x{W}")
+    y = torch.empty(N, Ho, Wo, Co, dtype=torch.float32, device=x.device)
+    z = torch.empty_like(y) if act == ACT_GELU else _e0(x)
+    ws = _ws(_query("hyb_conv2d_workspace", N, H, W, Ci, Co, k, stride, padding, dilation), x.device)
+    lib.call("hyb_conv2d_fwd", x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr() if bias is not None else None, y.data_ptr(),
+             z.data_ptr() if act == ACT_GELU else None, N, H, W, Ci, Co, k, stride, padding, dilation, act, ws.data_ptr(), ws.numel(), _stream())
+    return y, z
+
+
+def conv2d_fake(x, weight, bias, stride, padding, dilation, act):
+    N, H, W, _ = x.shape
+    k = weight.shape[2]
+    y = x.new_empty((N, _conv_out(H, k, stride, padding, dilation), _conv_out(W, k, stride, padding, dilation), weight.shape[0]), dtype=torch.float32)
+    return y, (torch.empty_like(y) if act == ACT_GELU else x.new_empty((0,), dtype=torch.float32))
+
+
+def conv2d_bwd_op(dy: Tensor, x: Tensor, weight: Tensor, saved: Tensor, has_bias: bool, need_dx: bool, stride: int, padding: int, dilation: int,
+                  act: int) -> Tuple[Tensor, Tensor, Tensor]:
+    _require_cuda(dy, x)
+    dy, x = _f32c(dy), _f32c(x)
+    N, H, W, Ci = x.shape
+    Co, k = weight.shape[0], weight.shape[2]
+    dx = torch.empty_like(x) if need_dx else _e0(x)
+    dw = torch.empty_like(weight, memory_format=torch.contiguous_format, dtype=torch.float32)
+    db = torch.empty(Co if has_bias else 0, dtype=torch.float32, device=x.device)
+    ws = _ws(_query("hyb_conv2d_bwd_workspace", N, H, W, Ci, Co, k, stride, padding, dilation), x.device)
+    lib.call("hyb_conv2d_bwd", dy.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), saved.data_ptr() if act != ACT_NONE else None,
+             dx.data_ptr() if need_dx else None, dw.data_ptr(), db.data_ptr() if has_bias else None, N, H, W, Ci, Co, k, stride, padding, dilation, act,
+             ws.data_ptr(), ws.numel(), _stream())
+    return dx, dw, db
+
+
+def conv2d_bwd_fake(dy, x, weight, saved, has_bias, need_dx, stride, padding, dilation, act):
+    return ((torch.empty_like(x) if need_dx else x.new_empty((0,))), torch.empty_like(weight, memory_format=torch.contiguous_format),
+            x.new_empty((weight.shape[0] if has_bias else 0,)))
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, act):
+        ctx.set_materialize_grads(False)
+        with _below_autograd():
+            y, z = torch.ops.hybrid.conv2d(x, weight, bias, stride, padding, dilation, act)
+        ctx.save_for_backward(x, weight, z if act == ACT_GELU else y if act != ACT_NONE else _e0(x))
+        ctx.cfg = (bias is not None, stride, padding, dilation, act)
+        ctx.mark_non_differentiable(z)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, dy, unused):
+        x, weight, saved = ctx.saved_tensors
+        has_bias, stride, padding, dilation, act = ctx.cfg
+        dx, dw, db = torch.ops.hybrid.conv2d_bwd(dy, x, weight, saved, has_bias, ctx.needs_input_grad[0], stride, padding, dilation, act)
+        return (dx if ctx.needs_input_grad[0] else None), dw, (db if has_bias else None), None, None, None, None
+
+
+def _bn_check(x, C):
+    if x.dim() != 4 or C % 4 != 0 or C < 4 or C > 1024 or 256 % (C // 4) != 0:
+        raise RuntimeError(f"bn2d: NHWC input with C in {{8, 16, 32, 64, 128, 256, 512, 1024}} (or 4) expected, got {tuple(x.shape)}")
+
+
+def bn2d_op(x: Tensor, weight: Tensor, bias: Tensor, residual: Optional[Tensor], running_mean: Optional[Tensor], running_var: Optional[Tensor],
+            training: bool, momentum: float, eps: float, relu: bool) -> Tuple[Tensor, Tensor]:
+    """nn.BatchNorm2d on NHWC x (+ residual) (+ ReLU) -> (y, coef [4,C] = a, b, mean, invstd).  In training mode the running
+    statistics are updated IN PLACE (they are module buffers, not differentiable)."""
+    _require_cuda(x, weight, bias)
+    x = _f32c(x)
+    C = x.shape[-1]
+    _bn_check(x, C)
+    if not training and (running_mean is None or running_var is None):
+        raise RuntimeError("bn2d: eval mode needs running statistics")
+    if residual is not None:
+        residual = _f32c(residual)
+        if residual.shape != x.shape:
+            raise RuntimeError(f"bn2d: residual {tuple(residual.shape)} vs input {tuple(x.shape)}")
+    P = x.numel() // C
+    y = torch.empty_like(x)
+    coef = torch.empty(4, C, dtype=torch.float32, device=x.device)
+    ws = _ws(_query("hyb_bn2d_workspace", P, C), x.device)
+    lib.call("hyb_bn2d_fwd", x.data_ptr(), _f32c(weight).data_ptr(), _f32c(bias).data_ptr(), _opt_ptr(residual), y.data_ptr(), coef.data_ptr(),
+             _opt_ptr(running_mean), _opt_ptr(running_var), P, C, float(eps), float(momentum), int(training), int(relu), ws.data_ptr(), ws.numel(),
+             _stream())
+    return y, coef
+
+
+def bn2d_fake(x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+    return x.new_empty(x.shape, dtype=torch.float32), x.new_empty((4, x.shape[-1]), dtype=torch.float32)
+
+
+def bn2d_bwd_op(dy: Tensor, x: Tensor, y: Tensor, weight: Tensor, coef: Tensor, training: bool, relu: bool,
+                has_residual: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """-> (dx, dresidual (empty unless has_residual), dweight, dbias)"""
+    _require_cuda(dy, x)
+    dy, x = _f32c(dy), _f32c(x)
+    C = x.shape[-1]
+    _bn_check(x, C)
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if has_residual else _e0(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _ws(_query("hyb_bn2d_workspace", P, C), x.device)
+    lib.call("hyb_bn2d_bwd", dy.data_ptr(), x.data_ptr(), y.data_ptr() if relu else None, _f32c(weight).data_ptr(), coef.data_ptr(), dx.data_ptr(),
+             dres.data_ptr() if has_residual else None, dg.data_ptr(), db.data_ptr(), P, C, int(training), int(relu), ws.data_ptr(), ws.numel(),
+             _stream())
+    return dx, dres, dg, db
+
+
+def bn2d_bwd_fake(dy, x, y, weight, coef, training, relu, has_residual):
+    C = x.shape[-1]
+    return torch.empty_like(x), (torch.empty_like(x) if has_residual else x.new_empty((0,))), x.new_empty((C,)), x.new_empty((C,))
+
+
+class _Bn2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+        ctx.set_materialize_grads(False)
+        with _below_autograd():
+            y, coef = torch.ops.hybrid.bn2d(x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu)
+        ctx.save_for_backward(x, weight, coef, y if relu else _e0(x))
+        ctx.cfg = (training, relu, residual is not None)
+        ctx.mark_non_differentiable(coef)
+        return y, coef
+
+    @staticmethod
+    def backward(ctx, dy, unused):
+        x, weight, coef, y = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        dx, dres, dg, db = torch.ops.hybrid.bn2d_bwd(dy, x, y, weight, coef, training, relu, has_res)
+        return dx, dg, db, (dres if has_res else None), None, None, None, None, None, None
+
+
+def dropout2d_op(x: Tensor, p: float, seed: int, seed_inc: Optional[Tensor] = None) -> Tensor:
+    """nn.Dropout2d(p) in train mode on NHWC x: whole (image, channel) planes are dropped."""
+    _require_cuda(x)
+    x = _f32c(x)
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    lib.call("hyb_dropout2d", x.data_ptr(), y.data_ptr(), N, H * W, C, float(p), seed, _opt_ptr(seed_inc), _stream())
+    return y
+
+
+class _Dropout2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, seed_inc):
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (p, seed)
+        ctx.seed_inc = seed_inc
+        with _below_autograd():
+            return torch.ops.hybrid.dropout2d(x, p, seed, seed_inc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return torch.ops.hybrid.dropout2d(dy, *ctx.cfg, ctx.seed_inc), None, None, None
+
+
+_define("conv2d", "(Tensor x, Tensor weight, Tensor? bias, int stride, int padding, int dilation, int act) -> (Tensor, Tensor)", conv2d_op, conv2d_fake,
+        _Conv2dFn.apply)
+_define("conv2d_bwd", "(Tensor dy, Tensor x, Tensor weight, Tensor saved, bool has_bias, bool need_dx, int stride, int padding, int dilation, int act) "
+        "-> (Tensor, Tensor, Tensor)", conv2d_bwd_op, conv2d_bwd_fake)
+_define("bn2d", "(Tensor x, Tensor weight, Tensor bias, Tensor? residual, Tensor(a!)? running_mean, Tensor(b!)? running_var, bool training, "
+        "float momentum, float eps, bool relu) -> (Tensor, Tensor)", bn2d_op, bn2d_fake, _Bn2dFn.apply)
+_define("bn2d_bwd", "(Tensor dy, Tensor x, Tensor y, Tensor weight, Tensor coef, bool training, bool relu, bool has_residual) "
+        "-> (Tensor, Tensor, Tensor, Tensor)", bn2d_bwd_op, bn2d_bwd_fake)
+_define("dropout2d", "(Tensor x, float p, int seed, Tensor? seed_inc=None) -> Tensor", dropout2d_op, fct_dropout_fake,
+        lambda x, p, seed, seed_inc=None: _Dropout2dFn.apply(x, p, seed, seed_inc))
 _define("fct_conv", "(Tensor x, Tensor weight, Tensor? bias, int dilation, int act) -> (Tensor, Tensor)", fct_conv_op, fct_conv_fake, _FctConvFn.apply)
 _define("fct_conv_bwd", "(Tensor dy, Tensor x, Tensor weight, Tensor saved, bool has_bias, bool need_dx, int dilation, int act) -> (Tensor, Tensor, Tensor)",
         fct_conv_bwd_op, fct_conv_bwd_fake)
