@@ -18,9 +18,9 @@ with ``marshal`` and an opcode table, never executed).  What the bytecode fixes,
 Module and state-dict names are the reference's (``conv1.weight``, ``layer1.0.downsample.0.weight``, ``bn5.running_var`` ..), so a
 checkpoint written by its ``train`` loads unchanged.  The submodules own the parameters and are never called: every step runs as a
 ``torch.ops.hybrid`` operator (conv2d, bn2d with the residual add and ReLU fused, dropout2d) on NHWC fp32 arrays, forward and
-backward in exact fp32.  Clips are fed frame-folded, ``[B*T, 3, 256, 256]``.  There is no CPU fallback.  Parity: the oracle
-(``oracle/encoder32k_ref.py``) restates the same bytecode with torch's own CPU operators; nothing executable of the reference exists
-for this model, so it is "parity unpinned" (DESIGN.md section 12).
+backward in exact fp32.  Clips are fed frame-folded, ``[B*T, 3, 256, 256]``.  There is no CPU fallback.  Parity: the tests compare
+against a CPU restatement of the same bytecode on torch's own operators; nothing executable of the reference exists for this model,
+so it is "parity unpinned" (DESIGN.md section 12).
 """
 import torch
 import torch.nn as nn
