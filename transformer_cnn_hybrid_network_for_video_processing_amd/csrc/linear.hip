@@ -330,6 +330,103 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tall GEMM for the pixel side (M = N*H*W rows, up to millions: the im2col convolutions of FCT and Encoder_32K):
+//   C[mo][no] = sum_r A[mo][r] * B[no][r]  (+ bias, ReLU, accumulate), all fp32, exact-fp32 MFMA.
+// A is streamed from HBM exactly once per column tile; B (the packed weights, <= a few MB) stays in L2.  A workgroup is four
+// independent waves stacked in M (no LDS, no barrier); a wave owns 32 rows x NT*16 columns and walks K in steps of 32 with its
+// fragments double-buffered in registers (the loads of step s+1 are issued before the MFMAs of step s).  The product is formed
+// TRANSPOSED (weights as the first MFMA operand), so a lane ends up with 4 consecutive columns of one row: 16-byte stores.
+// Workgroup -> tile map is XCD-aware: workgroups b, b+8, b+16, .. (same XCD, same L2) take the column tiles of ONE 128-row
+// block, so the re-reads of A by the other column tiles hit that L2 instead of HBM.
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_nt_tall_kernel(GemmArgs args, int tiles_n, int row_blocks) {
+    const GemmGroup grp = args.g[0];
+    const float* A = (const float*)grp.A;
+    const float* B = (const float*)grp.B;
+    float* C = (float*)grp.C;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int tn = seq % tiles_n, rb = (seq / tiles_n) * 8 + xcd;
+    if (rb >= row_blocks) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int m0 = rb * 128 + wave * 32, n0 = tn * (NT * 16);
+    if (m0 >= args.Mo) return;
+    const float* arow[2];
+    const float* brow[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = m0 + i * 16 + p; if (r > args.Mo - 1) r = args.Mo - 1;
+        arow[i] = A + (long long)r * args.lda + 8 * q;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int c = n0 + j * 16 + p; if (c > args.No - 1) c = args.No - 1;
+        brow[j] = B + (long long)c * args.ldb + 8 * q;
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int R = args.R;
+    Frag<float> a[2][2], b[2][NT];
+    auto load_step = [&](int buf, int k0) {
+        const bool ok = (k0 + 8 * q + 8) <= R;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { if (ok) frag_load(a[buf][i], arow[i] + k0); else frag_zero(a[buf][i]); }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { if (ok) frag_load(b[buf][j], brow[j] + k0); else frag_zero(b[buf][j]); }
+    };
+    auto mma_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma32(b[buf][j], a[buf][i], acc[i][j]);
+    };
+    load_step(0, 0);
+    for (int k0 = 0; k0 < R; k0 += 64) {
+        if (k0 + 32 < R) load_step(1, k0 + 32);
+        mma_step(0);
+        if (k0 + 32 < R) {
+            if (k0 + 64 < R) load_step(0, k0 + 64);
+            mma_step(1);
+        }
+    }
+    const bool vec = (args.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mo = m0 + i * 16 + p;
+        if (mo >= args.Mo) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int no = n0 + j * 16 + 4 * q;
+            if (no >= args.No) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float* dst = C + (long long)mo * args.ldc + no;
+            if (vec && no + 4 <= args.No) {
+                if (grp.bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(grp.bias + no); v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3]; }
+                if (args.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (args.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(dst); v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (no + r >= args.No) continue;
+                    float t = v[r];
+                    if (grp.bias) t += grp.bias[no + r];
+                    if (args.relu) t = fmaxf(t, 0.f);
+                    if (args.accumulate) t += dst[r];
+                    dst[r] = t;
+                }
+            }
+        }
+    }
+}
+
 // fp32 master weight W[N][K] -> T copy Wc[N][K] and T transpose Wt[K][N] (one 32x32 tile per block, grouped over blockIdx.z)
 struct ConvertArgs {
     const float* W[18];
@@ -504,7 +601,18 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
     // few tiles (M = 128, N = 512: 64 workgroups on 256 CUs): eight waves split K to shorten the per-wave load/MFMA chain
     static const int w8env = getenv("HYB_GEMM_W8") ? atoi(getenv("HYB_GEMM_W8")) : 1;
     const bool w8 = w8env && (long long)grid.x * grid.y * grid.z <= 256 && R >= 256;
-    if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
+    static const int tall_env = getenv("HYB_GEMM_TALL") ? atoi(getenv("HYB_GEMM_TALL")) : 1;
+    if (dtype == HYB_F32 && tall_env && groups == 1 && !Amask && Mo >= 2048) {
+        // pixel-side GEMMs (M = N*H*W): one pass over A per column tile, four independent waves per workgroup
+        const int row_blocks = hyb_cdiv(Mo, 128);
+        const int nt = No > 32 ? 4 : No > 16 ? 2 : 1;
+        const int tiles_n = hyb_cdiv(No, nt * 16);
+        const long long blocks = (long long)hyb_cdiv(row_blocks, 8) * tiles_n * 8;
+        if (blocks > 0x7fffffff) return HYB_E_ARG;
+        if (nt == 4) hipLaunchKernelGGL(gemm_nt_tall_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks);
+        else if (nt == 2) hipLaunchKernelGGL(gemm_nt_tall_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks);
+        else hipLaunchKernelGGL(gemm_nt_tall_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks);
+    } else if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 4>), grid, dim3(256), 0, st, a);
