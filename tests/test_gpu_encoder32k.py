@@ -42,6 +42,16 @@ CONV_CASES = [  # k, stride, pad, dil, ci, co, n, h, w, bias
     (3, 1, 1, 1, 16, 8, 2, 16, 16, True),       # tail conv5 with bias (src L88)
     (3, 1, 2, 2, 8, 8, 1, 12, 20, True),        # dilation (FCT's Wide_Focus geometry through the general entry point)
     (5, 3, 2, 1, 4, 8, 2, 20, 23, True),        # an unrelated geometry
+    # >= 2048 output pixels and power-of-two channels: the implicit-GEMM path (no patch matrix) in the forward and, at stride 1, the dgrad
+    (3, 1, 1, 1, 16, 24, 2, 40, 40, True),      # implicit forward; Co8 = 24 is not a power of two: dgrad through col2im
+    (3, 1, 1, 1, 32, 16, 2, 36, 33, False),     # implicit forward and dgrad, odd width
+    (3, 1, 2, 2, 8, 8, 2, 36, 40, True),        # dilation 2
+    (3, 1, 3, 3, 16, 8, 1, 48, 48, True),       # dilation 3 (pad = dil*(k-1)/2)
+    (5, 1, 2, 1, 8, 16, 1, 48, 48, False),      # 5x5
+    (3, 1, 0, 1, 8, 8, 1, 50, 50, False),       # no padding: the output is smaller than the input
+    (1, 2, 0, 1, 32, 64, 2, 80, 80, False),     # 1x1 stride 2 gathered in place
+    (3, 2, 1, 1, 16, 16, 2, 90, 91, False),     # 3x3 stride 2: implicit forward, col2im dgrad
+    (3, 1, 1, 1, 64, 4, 1, 64, 64, True),       # Co = 4 -> Co8 = 8 (padded gradient channels)
 ]
 
 

@@ -12,11 +12,15 @@
 //   MaxPool2d(2), AvgPool2d(2,2), Upsample(x2 nearest), cat, add   FCT.py:147,170,180,222,238-240
 //   DiceLoss                                                   Metrics.py:5-22
 #include <math.h>
+#include <stdlib.h>
 #include "hyb_common.h"
 #include "conv_geo.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+bool hyb_conv_implicit_ok(int Ci, long long rows);
+int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, float* y, int n_img, int H, int W, int Ci, int Ho, int Wo, int Co,
+                           int Kp, int k, int stride, int pad, int dil, int ldy, int relu, hipStream_t st);
 int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
                             float scale, hipStream_t st);
 
@@ -223,6 +227,19 @@ extern "C" int hyb_conv2d_fwd(const float* x, const float* w, const float* b, fl
     float* col = (float*)((char*)workspace + al256((size_t)Co * Kp * 4));
     hipLaunchKernelGGL(conv_pack_g_kernel, dim3(grid1((long long)Co * Kp)), dim3(256), 0, st, w, wp, Co, Ci, k * k, Kp);
     HYB_LAUNCH_CHECK();
+    static const int implicit_env = getenv("HYB_CONV_IMPLICIT") ? atoi(getenv("HYB_CONV_IMPLICIT")) : 1;
+    if (implicit_env && !ident && hyb_conv_implicit_ok(Ci, (long long)N * g.Ho * g.Wo) && (long long)N * g.Ho * g.Wo <= 0x7fffffff / 32 * 32 &&
+        (long long)N * H * W <= 0x7fffffff / 32 * 32) {
+        // no patch matrix: the GEMM gathers its A fragments from the image (all images in one launch)
+        float* gemm_out = ((act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) && z_out) ? z_out : y;
+        FCT_TRY(hyb_conv_implicit_gemm(x, wp, b, gemm_out, N, H, W, Ci, g.Ho, g.Wo, Co, Kp, k, stride, pad, dilation, Co, act == HYB_ACT_RELU, st));
+        if (act == HYB_ACT_GELU || act == HYB_ACT_SIGMOID) {
+            const long long n = (long long)N * g.Ho * g.Wo * Co;
+            hipLaunchKernelGGL(act_kernel, dim3(grid1(n)), dim3(256), 0, st, z_out ? (const float*)z_out : (const float*)y, y, n, act);
+            HYB_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const long long per_img = (long long)g.Ho * g.Wo * Kp * 4;
     long long nb = CONV_CHUNK_BYTES / per_img; if (nb < 1) nb = 1; if (nb > N) nb = N;
     for (int n0 = 0; n0 < N; n0 += (int)nb) {

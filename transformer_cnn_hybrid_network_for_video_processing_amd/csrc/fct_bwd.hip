@@ -16,6 +16,9 @@
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
 
+bool hyb_conv_implicit_ok(int Ci, long long rows);
+int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, float* y, int n_img, int H, int W, int Ci, int Ho, int Wo, int Co,
+                           int Kp, int k, int stride, int pad, int dil, int ldy, int relu, hipStream_t st);
 int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
                             void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st);
 
@@ -49,6 +52,17 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     dz[i] = v;
 }
 
+// weights of the input-gradient convolution (stride 1): wpd [Ci][k*k*Co8], column = (ky'*k + kx')*Co8 + co holds w[co][ci][k-1-ky'][k-1-kx']
+// (taps flipped, channel roles swapped), zero for co >= Co
+__global__ void conv_pack_flip_kernel(const float* __restrict__ w, float* __restrict__ wpd, int Co, int Ci, int k, int Co8) {
+    const int Kd = k * k * Co8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ci * Kd) return;
+    const int ci = i / Kd, r = i - ci * Kd;
+    const int tap = r / Co8, co = r - tap * Co8;
+    const int ky = tap / k, kx = tap - ky * k;
+    wpd[i] = co < Co ? w[(((long long)co * Ci + ci) * k + (k - 1 - ky)) * k + (k - 1 - kx)] : 0.f;
+}
 // wpt [Kp][Co8] <- w [Co][Ci][k][k] (column = tap*Ci + ci, kk = k*k taps), zero padded
 __global__ void conv_pack_t_kernel(const float* __restrict__ w, float* __restrict__ wpt, int Co, int Ci, int kk, int Kp, int Co8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -622,7 +636,15 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
     float* dbp = (float*)ws;   ws += al256((size_t)Co8 * 4);
     void* ws_w = ws;           ws += hyb_sliced_wgrad_workspace(Pc, Co8, Kp);
     void* ws_c = ws;
-    if (dx) { hipLaunchKernelGGL(conv_pack_t_kernel, dim3(grid1((long long)Kp * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, kk, Kp, Co8); HYB_LAUNCH_CHECK(); }
+    // stride-1 input gradient = a convolution of dz with the flipped kernel (padding dil*(k-1) - pad): the same implicit GEMM as the
+    // forward, no dcol matrix and no col2im pass
+    static const int implicit_env = getenv("HYB_CONV_IMPLICIT") ? atoi(getenv("HYB_CONV_IMPLICIT")) : 1;
+    const bool dgrad_implicit = implicit_env && dx && !ident && stride == 1 && dilation * (k - 1) >= pad && hyb_conv_implicit_ok(Co8, (long long)N * H * W);
+    if (dx && dgrad_implicit) {
+        hipLaunchKernelGGL(conv_pack_flip_kernel, dim3(grid1((long long)Ci * kk * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, k, Co8); HYB_LAUNCH_CHECK();
+    } else if (dx) {
+        hipLaunchKernelGGL(conv_pack_t_kernel, dim3(grid1((long long)Kp * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, kk, Kp, Co8); HYB_LAUNCH_CHECK();
+    }
     for (int n0 = 0, chunk = 0; n0 < N; n0 += (int)nb, ++chunk) {
         const int nn = N - n0 < nb ? N - n0 : (int)nb;
         const long long P = (long long)nn * g.Ho * g.Wo, off = (long long)n0 * g.Ho * g.Wo;
@@ -633,7 +655,10 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
             hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1(P * Co8)), dim3(256), 0, st, dy + off * Co, saved ? saved + off * Co : nullptr, dzb, P, Co, Co8, act);
             HYB_LAUNCH_CHECK();
         }
-        if (dx) {
+        if (dx && dgrad_implicit) {
+            FCT_TRY(hyb_conv_implicit_gemm(dz, wpt, nullptr, dx + off_in * Ci, nn, g.Ho, g.Wo, Co8, H, W, Ci, kk * Co8, k, 1, dilation * (k - 1) - pad,
+                                           dilation, Ci, 0, st));
+        } else if (dx) {
             const void* A[1] = {dz}; const void* B[1] = {wpt}; void* Cc[1] = {ident ? dx + off_in * Ci : col};
             FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, nullptr, 0, (int)P, Kp, Co8, Co8, Co8, Kp, 0, 0, st));
             if (!ident) { launch_col2im(col, dx + off_in * Ci, Pin, g, st); HYB_LAUNCH_CHECK(); }
