@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun): plain bench lines (configs 2 / 4 / 5, fp32, eager), kernel-trace summaries of
 # the bench command for configs 2/4/5, the two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) of config 2, the
-# attention micro-benchmark and the FCT bench.  Output under gpurun_out/prof_<tag>/; scripts/publish_profiles.py copies the summaries.
+# attention micro-benchmark, the FCT and Encoder_32K benches.  Output under gpurun_out/prof_<tag>/; scripts/publish_profiles.py copies the summaries.
 set -e
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -17,6 +17,7 @@ echo "bench lines done"
 python3 scripts/attn_microbench.py > $OUT/attention_microbench.json 2> $OUT/attention_microbench.err || true
 python3 scripts/fct_bench.py --cpu > $OUT/fct_bench.json 2> $OUT/fct_bench.err || true
 python3 scripts/s1_bench.py > $OUT/stage1_bench.json 2> /dev/null || true
+python3 scripts/enc32k_bench.py --frames 16 --cpu > $OUT/enc32k_bench.json 2> $OUT/enc32k_bench.err || true
 echo "micro benches done"
 cd /tmp && export TMPDIR=/tmp
 for C in 2 4 5; do
@@ -25,6 +26,9 @@ for C in 2 4 5; do
   rm -f $OUT/kt_c$C/kt_kernel_trace.csv
   echo "kernel trace config $C done"
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_enc32k -o kt -- python3 $REPO/scripts/enc32k_bench.py --frames 16 --reps 5 > $OUT/enc32k_under_rocprof.json 2> $OUT/kt_enc32k.err || true
+rm -f $OUT/kt_enc32k/kt_kernel_trace.csv
+echo "kernel trace Encoder_32K done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $REPO/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-fwd-bwd-only --no-pipeline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $REPO/bench.py --eager --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-fwd-bwd-only --no-pipeline > $OUT/pmc_write.json 2> $OUT/pmc_write.err

@@ -16,4 +16,6 @@ for c in (2, 4, 5):
 cp("attention_microbench.json", f"{tag}_attention_microbench.json")
 cp("fct_bench.json", f"{tag}_fct_bench.json")
 cp("stage1_bench.json", f"{tag}_stage1_bench.json")
+cp("enc32k_bench.json", f"{tag}_enc32k_bench.json")
+cp("kt_enc32k/kt_kernel_stats.csv", f"{tag}_kernel_stats_enc32k.csv")
 subprocess.check_call([sys.executable, os.path.join(root, "scripts", "pmc_traffic.py"), os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), tag])
