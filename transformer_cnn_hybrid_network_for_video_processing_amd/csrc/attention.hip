@@ -674,6 +674,97 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Heads of <= 4 features (FCT's two 12 544-token attentions: embed 8, 2 heads -- 157 M score pairs per image and head, where the
+// forward's time goes).  The 16x16x4 MFMA wastes most of itself on such a head (S = K Q^T pads 4 features to 8, O^T = V^T P^T fills 4 of
+// 16 output rows: 24 instructions x 32 cycles per 1024 pairs).  v_mfma_f32_4x4x1_16B (16 independent 4x4 outer products, 8 cycles; lane
+// l: block l/4, A row / B column l%4, result register r = A[block][r] * B[block][l%4] -- scripts/micro/mfma4x4_layout.hip) fits exactly:
+//   * a LANE owns one query (64 per wave, 256 per workgroup): B operand = its own 4 (pre-scaled) q features, held in registers;
+//   * S step: A operand = feature f of key (k0 + l%4) -> 4 instructions (f = 0..3) leave the lane's scores for keys k0..k0+3 in the 4
+//     result registers: the whole online softmax (max, exp2, sum, rescale) is per-lane arithmetic, no cross-lane step at all;
+//   * PV step: A operand = feature l%4 of key k0+i, B operand = the lane's own probability for that key -> 4 instructions (i = 0..3)
+//     accumulate the lane's 4 output features.  8 instructions x 8 cycles per 256 pairs: 4x fewer matrix cycles; the kernel is
+//     bound by the exponentials (one per pair, quarter rate) instead.
+// K rows and V columns of a 256-key block are staged in LDS (8 KB; the next block's rows are already in flight in registers); every
+// operand read is a 16-byte broadcast read (all 16 blocks read the same four addresses; V rows padded by 4 floats: conflict-free).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int F4_KB = 256, F4_VLD = F4_KB + 4;
+__global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            float* __restrict__ out, float* __restrict__ lse, int L, int H, int ld,
+                                                            float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) float Kimg[F4_KB * 4];        // [key][feature]
+    __shared__ __attribute__((aligned(16))) float Vt[4 * F4_VLD];         // [feature][key]
+    const int tid = threadIdx.x, j4 = tid & 3;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * 8;                 // padded head width 8
+    const int query = blockIdx.x * 256 + tid;
+    const int qrow = query < L ? query : L - 1;
+    f32x4 qv = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld);
+    qv *= scale_log2e;                                                     // scores come out in log2 units: exp2 below
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 kr = zero4, vr = zero4;
+    if (tid < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld); }
+    for (int kb = 0; kb < L; kb += F4_KB) {
+        __syncthreads();                                                   // every wave is done with the previous block's images
+        *reinterpret_cast<f32x4*>(Kimg + tid * 4) = kr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) Vt[f * F4_VLD + tid] = vr[f];
+        __syncthreads();
+        {
+            const int nx = kb + F4_KB + tid;                               // the next block's row of this thread: in flight during the block
+            kr = zero4; vr = zero4;
+            if (nx < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld); }
+        }
+        const int nk = L - kb < F4_KB ? L - kb : F4_KB;
+        for (int k0 = 0; k0 < nk; k0 += 16) {
+            f32x4 s[4];
+            f32x4 kk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { kk[g] = *reinterpret_cast<const f32x4*>(Kimg + (k0 + 4 * g + j4) * 4); s[g] = zero4; }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[f], s[g], 0, 0, 0);
+            if (k0 + 16 > nk) {                                            // ragged tail of the last block (uniform branch)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (k0 + 4 * g + r >= nk) s[g][r] = -INFINITY;
+            }
+            float mx = m;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mx = fmaxf(fmaxf(mx, fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
+            const float alpha = __builtin_amdgcn_exp2f(m - mx);           // m = -inf on the first group: 0
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - mx); sum += s[g][r]; }
+                o[g] *= alpha;
+            }
+            l = l * alpha + sum;
+            m = mx;
+            f32x4 vv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vv[g] = *reinterpret_cast<const f32x4*>(Vt + j4 * F4_VLD + k0 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) o[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][i], s[g][i], o[g], 0, 0, 0);
+        }
+    }
+    if (query >= L) return;
+    const f32x4 ot = ((o[0] + o[1]) + (o[2] + o[3])) * (1.f / l);
+    float* dst = out + base + (long long)query * ld;
+    *reinterpret_cast<f32x4*>(dst) = ot;
+    *reinterpret_cast<f32x4*>(dst + 4) = zero4;                            // the padded features of the head
+    if (lse) lse[(long long)blockIdx.y * L + query] = m * 0.6931471805599453f + __logf(l);     // natural-log sum-exp of the scaled scores
+}
+
 // delta[nh][q] = sum_d dO[q][d] * O[q][d]  (the softmax-backward row term; one thread per (image, head, query))
 template <typename T>
 __global__ void flash_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int N, int L, int H, int dhp, int ld) {
@@ -871,8 +962,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
 
 // Internal (fct.hip): out = softmax(q k^T * scale) v per (image, head), L tokens, heads of padded width dhp at stride ld
 int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
-                            float scale, hipStream_t st) {
+                            float scale, hipStream_t st, int dh_true) {
     if (!q || !k || !v || !out || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 || dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535) return HYB_E_ARG;
+    static const int f4_env = getenv("HYB_FLASH_FWD4") ? atoi(getenv("HYB_FLASH_FWD4")) : 1;
+    if (dtype == HYB_F32 && f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 4 && L >= 1024) {
+        // heads of <= 4 features: the 4x4x1 matrix instruction, a query per lane (features 4..7 of q, k, v are the zero padding)
+        hipLaunchKernelGGL(flash_fwd4_kernel, dim3(hyb_cdiv(L, 256), N * H), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
+                           (float*)out, lse, L, H, ld, scale * 1.4426950408889634f);
+        HYB_LAUNCH_CHECK();
+        return 0;
+    }
     const int es = dtype == HYB_F32 ? 4 : 2;
     int bytes = ((dhp + 15) / 16) * 16 * es;
     if ((bytes / 32) % 2 == 0) bytes += 32;

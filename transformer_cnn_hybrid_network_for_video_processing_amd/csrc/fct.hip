@@ -22,7 +22,7 @@ bool hyb_conv_implicit_ok(int Ci, long long rows);
 int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, float* y, int n_img, int H, int W, int Ci, int Ho, int Wo, int Co,
                            int Kp, int k, int stride, int pad, int dil, int ldy, int relu, hipStream_t st);
 int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
-                            float scale, hipStream_t st);
+                            float scale, hipStream_t st, int dh_true);
 
 namespace {
 
@@ -359,7 +359,7 @@ extern "C" int hyb_fct_mha_fwd(const float* q, const float* k, const float* v, c
         void* Cs[3] = {Q, K, V}; const float* bs[3] = {bin, bin + Cp, bin + 2 * Cp};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 3, As, Bs, Cs, bs, 0, (int)M, Cp, C, C, C, Cp, 0, 0, st));
     }
-    FCT_TRY(hyb_flash_attention_fwd(HYB_F32, Q, K, V, A, lse, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st));
+    FCT_TRY(hyb_flash_attention_fwd(HYB_F32, Q, K, V, A, lse, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st, dh));
     {   // out-projection
         const void* As[1] = {A}; const void* Bs[1] = {wout}; void* Cs[1] = {out}; const float* bs[1] = {out_b};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, As, Bs, Cs, bs, 0, (int)M, C, Cp, Cp, Cp, C, 0, 0, st));
