@@ -765,6 +765,184 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
     if (lse) lse[(long long)blockIdx.y * L + query] = m * 0.6931471805599453f + __logf(l);     // natural-log sum-exp of the scaled scores
 }
 
+// Backward of the same heads, the same way.  dQ kernel: a lane owns a QUERY and walks the keys (256-key blocks in LDS: K rows, K columns,
+// V rows): per 4 keys 4 instructions give its scores, 4 its dP = dO . V, the softmax backward dS = P (dP - delta) scale is per-lane
+// arithmetic (the row's log-sum-exp and delta are the lane's own scalars), 4 instructions accumulate dQ += dS K.
+__global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, float* __restrict__ dq, int L, int H, int ld,
+                                                               float scale) {
+    __shared__ __attribute__((aligned(16))) float Kr[F4_KB * 4];          // [key][feature]
+    __shared__ __attribute__((aligned(16))) float Vr[F4_KB * 4];
+    __shared__ __attribute__((aligned(16))) float Kt[4 * F4_VLD];         // [feature][key]
+    const int tid = threadIdx.x, j4 = tid & 3;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * 8;
+    const int query = blockIdx.x * 256 + tid;
+    const int qrow = query < L ? query : L - 1;
+    const float LOG2E = 1.4426950408889634f;
+    f32x4 qv = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld);
+    qv *= scale * LOG2E;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(dout + base + (long long)qrow * ld);
+    const float lse2 = lse[(long long)blockIdx.y * L + qrow] * LOG2E, dl = delta[(long long)blockIdx.y * L + qrow];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = zero4;
+    f32x4 kr = zero4, vr = zero4;
+    if (tid < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld); }
+    for (int kb = 0; kb < L; kb += F4_KB) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(Kr + tid * 4) = kr;
+        *reinterpret_cast<f32x4*>(Vr + tid * 4) = vr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) Kt[f * F4_VLD + tid] = kr[f];
+        __syncthreads();
+        {
+            const int nx = kb + F4_KB + tid;
+            kr = zero4; vr = zero4;
+            if (nx < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld); }
+        }
+        const int nk = L - kb < F4_KB ? L - kb : F4_KB;
+        for (int k0 = 0; k0 < nk; k0 += 16) {
+            f32x4 s[4], dp[4], kk[4], vv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                kk[g] = *reinterpret_cast<const f32x4*>(Kr + (k0 + 4 * g + j4) * 4);
+                vv[g] = *reinterpret_cast<const f32x4*>(Vr + (k0 + 4 * g + j4) * 4);
+                s[g] = zero4; dp[g] = zero4;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[f], s[g], 0, 0, 0);
+                    dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][f], gv[f], dp[g], 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - lse2) * (dp[g][r] - dl) * scale;
+            if (k0 + 16 > nk) {                                            // ragged tail: keys past the sequence contribute nothing
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (k0 + 4 * g + r >= nk) s[g][r] = 0.f;
+            }
+            f32x4 kt[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kt[g] = *reinterpret_cast<const f32x4*>(Kt + j4 * F4_VLD + k0 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kt[g][i], s[g][i], acc[g], 0, 0, 0);
+        }
+    }
+    if (query >= L) return;
+    float* dst = dq + base + (long long)query * ld;
+    *reinterpret_cast<f32x4*>(dst) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    *reinterpret_cast<f32x4*>(dst + 4) = zero4;
+}
+
+// dK / dV kernel: a lane owns a KEY and walks the queries (256-query blocks in LDS: q and dO as rows and as columns, the rows' log-sum-exp
+// and delta): per 4 queries 4 instructions give S^T, 4 give dP^T, then dV += P^T dO and dK += dS^T Q with 4 instructions each.  Queries
+// past the sequence are staged with lse = +inf: their probabilities are exactly 0, no tail branch.
+__global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                const float* __restrict__ delta, float* __restrict__ dk, float* __restrict__ dv, int L,
+                                                                int H, int ld, float scale) {
+    __shared__ __attribute__((aligned(16))) float Qr[F4_KB * 4];          // [query][feature]
+    __shared__ __attribute__((aligned(16))) float Gr[F4_KB * 4];
+    __shared__ __attribute__((aligned(16))) float Qt[4 * F4_VLD];         // [feature][query]
+    __shared__ __attribute__((aligned(16))) float Gt[4 * F4_VLD];
+    __shared__ __attribute__((aligned(16))) float Ls[F4_KB];              // log2-domain log-sum-exp per query
+    __shared__ __attribute__((aligned(16))) float Ds[F4_KB];              // delta per query
+    const int tid = threadIdx.x, j4 = tid & 3;
+    const int n = blockIdx.y / H, h = blockIdx.y - n * H;
+    const long long base = (long long)n * L * ld + h * 8;
+    const long long sbase = (long long)blockIdx.y * L;
+    const int key = blockIdx.x * 256 + tid;
+    const int krow = key < L ? key : L - 1;
+    const float LOG2E = 1.4426950408889634f;
+    f32x4 ks = *reinterpret_cast<const f32x4*>(k + base + (long long)krow * ld);
+    ks *= scale * LOG2E;
+    const f32x4 vo = *reinterpret_cast<const f32x4*>(v + base + (long long)krow * ld);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 adk[4], adv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { adk[g] = zero4; adv[g] = zero4; }
+    f32x4 qr = zero4, gr = zero4;
+    float lr = INFINITY, dr = 0.f;
+    if (tid < L) {
+        qr = *reinterpret_cast<const f32x4*>(q + base + (long long)tid * ld); gr = *reinterpret_cast<const f32x4*>(dout + base + (long long)tid * ld);
+        lr = lse[sbase + tid] * LOG2E; dr = delta[sbase + tid];
+    }
+    for (int qb = 0; qb < L; qb += F4_KB) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(Qr + tid * 4) = qr;
+        *reinterpret_cast<f32x4*>(Gr + tid * 4) = gr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { Qt[f * F4_VLD + tid] = qr[f]; Gt[f * F4_VLD + tid] = gr[f]; }
+        Ls[tid] = lr; Ds[tid] = dr;
+        __syncthreads();
+        {
+            const int nx = qb + F4_KB + tid;
+            qr = zero4; gr = zero4; lr = INFINITY; dr = 0.f;
+            if (nx < L) {
+                qr = *reinterpret_cast<const f32x4*>(q + base + (long long)nx * ld); gr = *reinterpret_cast<const f32x4*>(dout + base + (long long)nx * ld);
+                lr = lse[sbase + nx] * LOG2E; dr = delta[sbase + nx];
+            }
+        }
+        const int nq = L - qb < F4_KB ? L - qb : F4_KB;
+        for (int q0 = 0; q0 < nq; q0 += 16) {
+            f32x4 s[4], dp[4], qq[4], gg[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qq[g] = *reinterpret_cast<const f32x4*>(Qr + (q0 + 4 * g + j4) * 4);
+                gg[g] = *reinterpret_cast<const f32x4*>(Gr + (q0 + 4 * g + j4) * 4);
+                s[g] = zero4; dp[g] = zero4;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qq[g][f], ks[f], s[g], 0, 0, 0);
+                    dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gg[g][f], vo[f], dp[g], 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0 + 4 * g), d4 = *reinterpret_cast<const f32x4*>(Ds + q0 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[g][r] - l4[r]);          // 0 for the padding queries (lse = +inf)
+                    s[g][r] = pv;
+                    dp[g][r] = pv * (dp[g][r] - d4[r]) * scale;
+                }
+            }
+            f32x4 qt[4], gt[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qt[g] = *reinterpret_cast<const f32x4*>(Qt + j4 * F4_VLD + q0 + 4 * g);
+                gt[g] = *reinterpret_cast<const f32x4*>(Gt + j4 * F4_VLD + q0 + 4 * g);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    adv[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gt[g][i], s[g][i], adv[g], 0, 0, 0);
+                    adk[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qt[g][i], dp[g][i], adk[g], 0, 0, 0);
+                }
+        }
+    }
+    if (key >= L) return;
+    float* dkd = dk + base + (long long)key * ld;
+    float* dvd = dv + base + (long long)key * ld;
+    *reinterpret_cast<f32x4*>(dkd) = (adk[0] + adk[1]) + (adk[2] + adk[3]);
+    *reinterpret_cast<f32x4*>(dkd + 4) = zero4;
+    *reinterpret_cast<f32x4*>(dvd) = (adv[0] + adv[1]) + (adv[2] + adv[3]);
+    *reinterpret_cast<f32x4*>(dvd + 4) = zero4;
+}
+
 // delta[nh][q] = sum_d dO[q][d] * O[q][d]  (the softmax-backward row term; one thread per (image, head, query))
 template <typename T>
 __global__ void flash_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int N, int L, int H, int dhp, int ld) {
@@ -991,7 +1169,7 @@ int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void*
 
 // Internal (fct_bwd.hip): gradients of the long-sequence attention core.  lse from the forward pass; delta_ws: N*H*L floats of scratch.
 int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
-                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st) {
+                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st, int dh_true) {
     if (!q || !k || !v || !o || !dout || !lse || !delta_ws || !dq || !dk || !dv || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 ||
         dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535 || dtype != HYB_F32) return HYB_E_ARG;      // fp32 only so far (FCT runs in fp32)
     const int es = 4;
@@ -1002,6 +1180,16 @@ int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void*
     if (lds > 64 * 1024) return HYB_E_ARG;                       // 128-wide fp32 heads: 2 x 64 x 136 x 4 B = 68 KiB; FCT's widest head is 64
     const long long nq = (long long)N * H * L;
     hipLaunchKernelGGL(flash_delta_kernel<float>, dim3(hyb_cdiv(nq, 256)), dim3(256), 0, st, (const float*)o, (const float*)dout, delta_ws, N, L, H, dhp, ld);
+    static const int f4_env = getenv("HYB_FLASH_BWD4") ? atoi(getenv("HYB_FLASH_BWD4")) : 1;
+    if (f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 4 && L >= 1024) {      // heads of <= 4 features: the 4x4x1 matrix instruction
+        const dim3 grid4(hyb_cdiv(L, 256), N * H);
+        hipLaunchKernelGGL(flash_bwd4_dq_kernel, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                           (const float*)delta_ws, (float*)dq, L, H, ld, scale);
+        hipLaunchKernelGGL(flash_bwd4_dkv_kernel, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
+        HYB_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid(hyb_cdiv(L, 64), N * H);
 #define FLASH_BWD(DTC_) do { \
         hipLaunchKernelGGL((flash_bwd_dq_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \

@@ -20,7 +20,7 @@ bool hyb_conv_implicit_ok(int Ci, long long rows);
 int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, float* y, int n_img, int H, int W, int Ci, int Ho, int Wo, int Co,
                            int Kp, int k, int stride, int pad, int dil, int ldy, int relu, hipStream_t st);
 int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
-                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st);
+                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st, int dh_true);
 
 namespace {
 
@@ -877,7 +877,7 @@ extern "C" int hyb_fct_mha_bwd(const float* dout, const float* q, const float* k
         FCT_TRY(hyb_gemm_nt(HYB_F32, 1, As, Bs, Cs, nullptr, 0, (int)M, Cp, C, C, C, Cp, 0, 0, st));
         FCT_TRY(hyb_sliced_wgrad_cs(dout, C, A, Cp, dwout, dout_b, M, C, Cp, 0, ws_w, ws_c, st));
     }
-    FCT_TRY(hyb_flash_attention_bwd(HYB_F32, Q, K, V, A, dA, lse, delta, dQ, dK, dV, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st));
+    FCT_TRY(hyb_flash_attention_bwd(HYB_F32, Q, K, V, A, dA, lse, delta, dQ, dK, dV, N, L, heads, dhp, Cp, 1.0f / sqrtf((float)dh), st, dh));
     {   // in-projection: d(inputs) = dQ Win (three GEMMs in one launch), dWin_j = dQ_j^T input_j, dbin_j = column sums
         const void* As[3] = {dQ, dK, dV}; const void* Bs[3] = {winT, winT + (size_t)C * Cp, winT + (size_t)2 * C * Cp}; void* Cs[3] = {dq, dk, dv};
         FCT_TRY(hyb_gemm_nt(HYB_F32, 3, As, Bs, Cs, nullptr, 0, (int)M, C, Cp, Cp, Cp, C, 0, 0, st));
