@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __re
     const f32x4 gv = *reinterpret_cast<const f32x4*>(dout + base + (long long)qrow * ld);
     const float lse2 = lse[(long long)blockIdx.y * L + qrow] * LOG2E, dl = delta[(long long)blockIdx.y * L + qrow];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 nlse4 = f32x4{-lse2, -lse2, -lse2, -lse2}, ndl4 = f32x4{-dl, -dl, -dl, -dl};
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = zero4;
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __re
             for (int g = 0; g < 4; ++g) {
                 kk[g] = *reinterpret_cast<const f32x4*>(Kr + (k0 + 4 * g + j4) * 4);
                 vv[g] = *reinterpret_cast<const f32x4*>(Vr + (k0 + 4 * g + j4) * 4);
-                s[g] = zero4; dp[g] = zero4;
+                s[g] = nlse4; dp[g] = ndl4;                               // the accumulators start at -lse and -delta: the subtractions are free
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __re
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - lse2) * (dp[g][r] - dl) * scale;
+                for (int r = 0; r < 4; ++r) s[g][r] = __builtin_amdgcn_exp2f(s[g][r]) * dp[g][r];       // (the factor `scale` is applied once, to the sum)
             if (k0 + 16 > nk) {                                            // ragged tail: keys past the sequence contribute nothing
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __re
     }
     if (query >= L) return;
     float* dst = dq + base + (long long)query * ld;
-    *reinterpret_cast<f32x4*>(dst) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    *reinterpret_cast<f32x4*>(dst) = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * scale;
     *reinterpret_cast<f32x4*>(dst + 4) = zero4;
 }
 
@@ -855,8 +856,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float Gr[F4_KB * 4];
     __shared__ __attribute__((aligned(16))) float Qt[4 * F4_VLD];         // [feature][query]
     __shared__ __attribute__((aligned(16))) float Gt[4 * F4_VLD];
-    __shared__ __attribute__((aligned(16))) float Ls[F4_KB];              // log2-domain log-sum-exp per query
-    __shared__ __attribute__((aligned(16))) float Ds[F4_KB];              // delta per query
+    __shared__ __attribute__((aligned(16))) float Ls[F4_KB];              // MINUS the log2-domain log-sum-exp per query
+    __shared__ __attribute__((aligned(16))) float Ds[F4_KB];              // MINUS delta per query
     const int tid = threadIdx.x, j4 = tid & 3;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * 8;
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
         *reinterpret_cast<f32x4*>(Gr + tid * 4) = gr;
 #pragma unroll
         for (int f = 0; f < 4; ++f) { Qt[f * F4_VLD + tid] = qr[f]; Gt[f * F4_VLD + tid] = gr[f]; }
-        Ls[tid] = lr; Ds[tid] = dr;
+        Ls[tid] = -lr; Ds[tid] = -dr;
         __syncthreads();
         {
             const int nx = qb + F4_KB + tid;
@@ -900,7 +901,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
             for (int g = 0; g < 4; ++g) {
                 qq[g] = *reinterpret_cast<const f32x4*>(Qr + (q0 + 4 * g + j4) * 4);
                 gg[g] = *reinterpret_cast<const f32x4*>(Gr + (q0 + 4 * g + j4) * 4);
-                s[g] = zero4; dp[g] = zero4;
+                s[g] = *reinterpret_cast<const f32x4*>(Ls + q0 + 4 * g);        // accumulators start at -lse / -delta of the four queries
+                dp[g] = *reinterpret_cast<const f32x4*>(Ds + q0 + 4 * g);
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -910,15 +912,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
                     dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gg[g][f], vo[f], dp[g], 0, 0, 0);
                 }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + q0 + 4 * g), d4 = *reinterpret_cast<const f32x4*>(Ds + q0 + 4 * g);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[g][r] - l4[r]);          // 0 for the padding queries (lse = +inf)
+                    const float pv = __builtin_amdgcn_exp2f(s[g][r]);                   // 0 for the padding queries (lse = +inf)
                     s[g][r] = pv;
-                    dp[g][r] = pv * (dp[g][r] - d4[r]) * scale;
+                    dp[g][r] *= pv;                                                    // (the factor `scale` is applied once, to dK)
                 }
-            }
             f32x4 qt[4], gt[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
     if (key >= L) return;
     float* dkd = dk + base + (long long)key * ld;
     float* dvd = dv + base + (long long)key * ld;
-    *reinterpret_cast<f32x4*>(dkd) = (adk[0] + adk[1]) + (adk[2] + adk[3]);
+    *reinterpret_cast<f32x4*>(dkd) = ((adk[0] + adk[1]) + (adk[2] + adk[3])) * scale;
     *reinterpret_cast<f32x4*>(dkd + 4) = zero4;
     *reinterpret_cast<f32x4*>(dvd) = (adv[0] + adv[1]) + (adv[2] + adv[3]);
     *reinterpret_cast<f32x4*>(dvd + 4) = zero4;
