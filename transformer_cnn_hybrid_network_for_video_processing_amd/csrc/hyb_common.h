@@ -136,15 +136,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t hyb_rsrc(const void* p, unsign
 // ---------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------
+// DPP row rotations inside the four 16-lane rows (v_add_f32_dpp: no LDS crossbar round trips -- six dependent ds_bpermute of the
+// shuffle form cost ~0.7 us, a visible share of a 4 us latency-bound kernel), then the four row totals through v_readlane.  Every lane
+// gets the same value; the order of the additions is fixed.
+template <int CTRL> __device__ __forceinline__ float hyb_dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += hyb_dpp_mov<0x128>(v);      // row_ror:8
+    v += hyb_dpp_mov<0x124>(v);      // row_ror:4
+    v += hyb_dpp_mov<0x122>(v);      // row_ror:2
+    v += hyb_dpp_mov<0x121>(v);      // row_ror:1
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, hyb_dpp_mov<0x128>(v));
+    v = fmaxf(v, hyb_dpp_mov<0x124>(v));
+    v = fmaxf(v, hyb_dpp_mov<0x122>(v));
+    v = fmaxf(v, hyb_dpp_mov<0x121>(v));
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // reduce across the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float group16_sum(float v) {

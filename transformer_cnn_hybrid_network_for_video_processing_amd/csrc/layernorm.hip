@@ -8,23 +8,37 @@ namespace {
 
 constexpr int LN_MAXC = 4;        // chunks of 8 features per lane: D <= 64*8*4 = 2048
 
+// Latency is all this kernel has (128 rows of 512 features): every global load of a row -- x, skip, gamma, beta and the dropout counter --
+// is issued before the first wait, so the kernel pays ONE memory round trip (the first version loaded skip / gamma / beta after the two
+// reductions and the counter before anything else: three dependent round trips, 4.2 us hot; reductions by DPP, not ds_bpermute).
 template <typename T>
 __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               T* __restrict__ y, float* __restrict__ stats, int M, int D, float eps,
                                                               float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
-    if (seed_inc) seed += *seed_inc;                            // device-side step counter: the same captured launch draws a fresh mask per replay
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nchunk = D >> 3;
-    Vec8<T> xv[LN_MAXC];
-    float sum = 0.f;
+    Vec8<T> xv[LN_MAXC], sk[LN_MAXC];
+    Vec8<float> gm[LN_MAXC], bt[LN_MAXC];
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunk) {
             xv[c].load(x + (long long)row * D + ch * 8);
+            sk[c].load(skip + (long long)row * D + ch * 8);
+            gm[c].load(gamma + ch * 8);
+            bt[c].load(beta + ch * 8);
+        }
+    }
+    unsigned long long inc = 0;
+    if (p_drop > 0.f && seed_inc) inc = *seed_inc;              // device-side step counter: the same captured launch draws a fresh mask per replay
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += xv[c].get(j);
         }
@@ -43,16 +57,16 @@ __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restric
     const float rstd = rsqrtf(var + eps);
     if (lane == 0) { stats[row] = mean; stats[M + row] = rstd; }
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    seed += inc;
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunk) {
-            Vec8<T> sk, o;
-            sk.load(skip + (long long)row * D + ch * 8);
+            Vec8<T> o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = ch * 8 + j;
-                float v = ((xv[c].get(j) - mean) * rstd * gamma[col] + beta[col] + sk.get(j)) * out_scale;
+                float v = ((xv[c].get(j) - mean) * rstd * gm[c].get(j) + bt[c].get(j) + sk[c].get(j)) * out_scale;
                 if (p_drop > 0.f) v *= dropout_mult(seed, (unsigned long long)row * D + col, p_drop, inv_keep);
                 o.set(j, v);
             }
@@ -68,10 +82,14 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
                                                               const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip,
                                                               int accumulate_dskip, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int M, int D, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
-    if (seed_inc) seed += *seed_inc;                            // device-side step counter: the same captured launch draws a fresh mask per replay
     const int lane = threadIdx.x & 63;
     const int nchunk = D >> 3;
     const int total_waves = gridDim.x * 4;
+    // gamma is row-independent: loaded once, together with the first row's operands (one memory round trip; see the forward kernel)
+    Vec8<float> gmv[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) { const int ch = lane + 64 * c; if (ch < nchunk) gmv[c].load(gamma + ch * 8); }
+    bool seeded = false;
     float dg[LN_MAXC][8], db[LN_MAXC][8];
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c)
@@ -79,17 +97,27 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
         for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += total_waves) {
+        Vec8<T> dvv[LN_MAXC], xvv[LN_MAXC], dsv[LN_MAXC];
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {                    // every load of the row before the first wait
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                dvv[c].load(dy + (long long)row * D + ch * 8);
+                xvv[c].load(x + (long long)row * D + ch * 8);
+                if (accumulate_dskip) dsv[c].load(dskip + (long long)row * D + ch * 8);
+            }
+        }
         const float mean = stats[row], rstd = stats[M + row];
+        if (!seeded) { if (p_drop > 0.f && seed_inc) seed += *seed_inc; seeded = true; }      // device-side step counter (fresh mask per replay)
         float gl[LN_MAXC][8], xh[LN_MAXC][8];      // g = d(ln_out) * gamma ; xhat
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < LN_MAXC; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nchunk) {
-                Vec8<T> dv, xv, ds;
-                dv.load(dy + (long long)row * D + ch * 8);
-                xv.load(x + (long long)row * D + ch * 8);
-                if (accumulate_dskip) ds.load(dskip + (long long)row * D + ch * 8);
+                const Vec8<T>& dv = dvv[c];
+                const Vec8<T>& xv = xvv[c];
+                Vec8<T> ds = dsv[c];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int col = ch * 8 + j;
@@ -99,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
                     xh[c][j] = xhat;
                     dg[c][j] += d * xhat;
                     db[c][j] += d;
-                    const float g = d * gamma[col];
+                    const float g = d * gmv[c].get(j);
                     gl[c][j] = g;
                     s1 += g;
                     s2 += g * xhat;
