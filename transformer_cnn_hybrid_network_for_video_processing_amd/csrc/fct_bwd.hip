@@ -223,10 +223,14 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
 }
 // out[i] (+)= sum_s part[s][i], fixed order: 256 threads = 32 columns x 8 slab groups (a column's slabs are split over 8 threads,
 // four loads in flight each, then combined through LDS) -- with ~2000 slabs a thread per column was a 2000-deep serial chain
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long n, int accumulate) {
+// A second, independent sum (the bias gradient's column partials) rides in the same launch: blocks >= nb1 work on (part2, out2, n2).
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long n, int accumulate,
+                                                       int nb1, const float* __restrict__ part2, float* __restrict__ out2, long long n2) {
     __shared__ float red[8][33];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long long i = (long long)blockIdx.x * 32 + col;
+    int blk = blockIdx.x;
+    if (blk >= nb1) { blk -= nb1; part = part2; out = out2; n = n2; }
+    const long long i = (long long)blk * 32 + col;
     float a = 0.f;
     if (i < n) {
         int j = grp;
@@ -578,8 +582,11 @@ int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, floa
         else if (ktl == 4) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
         else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
     }
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv((long long)Nn * K, 32)), dim3(256), 0, st, (const float*)ws, out, S, (long long)Nn * K, accumulate);
-    if (colsum) hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv(Nn, 32)), dim3(256), 0, st, (const float*)cpart, colsum, S, (long long)Nn, accumulate);
+    {   // the slab sums of dW and (when wanted) of the bias gradient: one launch
+        const int nb1 = hyb_cdiv((long long)Nn * K, 32), nb2 = colsum ? hyb_cdiv(Nn, 32) : 0;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(nb1 + nb2), dim3(256), 0, st, (const float*)ws, out, S, (long long)Nn * K, accumulate, nb1,
+                           (const float*)cpart, colsum, (long long)Nn);
+    }
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -597,7 +604,8 @@ size_t hyb_sliced_colsum_workspace(long long P, int C) {
 int hyb_sliced_colsum(const float* v, int ldv, float* out, long long P, int C, int accumulate, void* ws, hipStream_t st) {
     const int S = hyb_cdiv(P, SLICE_ROWS);
     hipLaunchKernelGGL(colsum_slice_kernel, dim3(S), dim3(256), 0, st, v, ldv, (float*)ws, P, C, SLICE_ROWS);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, out, S, (long long)C, accumulate);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(hyb_cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, out, S, (long long)C, accumulate, hyb_cdiv(C, 32),
+                       (const float*)nullptr, (float*)nullptr, 0ll);
     HYB_LAUNCH_CHECK();
     return 0;
 }
@@ -640,6 +648,9 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
     // forward, no dcol matrix and no col2im pass
     static const int implicit_env = getenv("HYB_CONV_IMPLICIT") ? atoi(getenv("HYB_CONV_IMPLICIT")) : 1;
     const bool dgrad_implicit = implicit_env && dx && !ident && stride == 1 && dilation * (k - 1) >= pad && hyb_conv_implicit_ok(Co8, (long long)N * H * W);
+    // unpadded shapes need no repacking of the results: the slab sums land in dw (1x1: [Co][Ci] is the packed layout) and db directly
+    float* dw_dst = (k == 1 && Kp == Ci && Co8 == Co) ? dw : dwp;
+    float* db_dst = (Co8 == Co) ? db : dbp;
     if (dx && dgrad_implicit) {
         hipLaunchKernelGGL(conv_pack_flip_kernel, dim3(grid1((long long)Ci * kk * Co8)), dim3(256), 0, st, w, wpt, Co, Ci, k, Co8); HYB_LAUNCH_CHECK();
     } else if (dx) {
@@ -664,10 +675,10 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
             if (!ident) { launch_col2im(col, dx + off_in * Ci, Pin, g, st); HYB_LAUNCH_CHECK(); }
         }
         if (!ident) { launch_im2col(x + off_in * Ci, col, P, g, st); HYB_LAUNCH_CHECK(); }
-        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, ident ? x + off_in * Ci : col, Kp, dwp, db ? dbp : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
+        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, ident ? x + off_in * Ci : col, Kp, dw_dst, db ? db_dst : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
     }
-    hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * kk)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, kk, Kp);
-    if (db) { hipError_t e = hipMemcpyAsync(db, dbp, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
+    if (dw_dst != dw) hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * kk)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, kk, Kp);
+    if (db && db_dst != db) { hipError_t e = hipMemcpyAsync(db, dbp, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
     HYB_LAUNCH_CHECK();
     return 0;
 }
