@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
 // operand read is a 16-byte broadcast read (all 16 blocks read the same four addresses; V rows padded by 4 floats: conflict-free).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int F4_KB = 256, F4_VLD = F4_KB + 4;
+constexpr float F4_LAZY = 12.f;           // the exponent's reference point moves when a score exceeds it by more than 2^12 (fp32 sums: far from overflow)
 __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             float* __restrict__ out, float* __restrict__ lse, int L, int H, int ld,
                                                             float scale_log2e) {
@@ -701,11 +702,20 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
     const int qrow = query < L ? query : L - 1;
     f32x4 qv = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld);
     qv *= scale_log2e;                                                     // scores come out in log2 units: exp2 below
-    float m = -INFINITY, l = 0.f;
+    // LAZY RESCALING.  m is a per-lane reference point of the exponent, not the running maximum: the score accumulators START at -m, so
+    // the matrix instruction delivers s - m and p = exp2(s - m) needs no subtraction; m moves (with the usual rescale of l and o) only
+    // when some score exceeds it by more than 2^F4_LAZY -- after the first keys that is rare, and the test is one wave-uniform branch.
+    // softmax is shift-invariant, so the result is the same function; lse = m ln2 + ln(l) stays exact.  m starts at the score of key 0.
+    float l = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) o[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m;
+    {
+        const f32x4 k0v = *reinterpret_cast<const f32x4*>(k + base);
+        m = (qv[0] * k0v[0] + qv[1] * k0v[1]) + (qv[2] * k0v[2] + qv[3] * k0v[3]);
+    }
     f32x4 kr = zero4, vr = zero4;
     if (tid < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld); }
     for (int kb = 0; kb < L; kb += F4_KB) {
@@ -723,8 +733,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
         for (int k0 = 0; k0 < nk; k0 += 16) {
             f32x4 s[4];
             f32x4 kk[4];
+            const f32x4 nm4 = f32x4{-m, -m, -m, -m};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { kk[g] = *reinterpret_cast<const f32x4*>(Kimg + (k0 + 4 * g + j4) * 4); s[g] = zero4; }
+            for (int g = 0; g < 4; ++g) { kk[g] = *reinterpret_cast<const f32x4*>(Kimg + (k0 + 4 * g + j4) * 4); s[g] = nm4; }
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -735,19 +746,27 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (k0 + 4 * g + r >= nk) s[g][r] = -INFINITY;
             }
-            float mx = m;
+            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mx = fmaxf(fmaxf(mx, fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
-            const float alpha = __builtin_amdgcn_exp2f(m - mx);           // m = -inf on the first group: 0
+            for (int g = 1; g < 4; ++g) mx = fmaxf(fmaxf(mx, fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
+            if (__builtin_amdgcn_ballot_w64(mx > F4_LAZY) != 0ull) {       // rare after the first keys: move the reference of the lanes that need it
+                const float d = mx > F4_LAZY ? mx : 0.f;
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                m += d;
+                l *= alpha;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    o[g] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[g][r] -= d;
+                }
+            }
             float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - mx); sum += s[g][r]; }
-                o[g] *= alpha;
-            }
-            l = l * alpha + sum;
-            m = mx;
+                for (int r = 0; r < 4; ++r) { s[g][r] = __builtin_amdgcn_exp2f(s[g][r]); sum += s[g][r]; }
+            l += sum;
             f32x4 vv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) vv[g] = *reinterpret_cast<const f32x4*>(Vt + j4 * F4_VLD + k0 + 4 * g);
