@@ -374,7 +374,8 @@ int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, const float*
  * `out += residual` and nn.ReLU (src L44-52): y = relu?( (x - mean) / sqrt(var + eps) * gamma + beta (+ residual) ).
  * training != 0: batch statistics (biased variance), running_mean / running_var (or NULL) updated in place with `momentum` and the
  * unbiased variance, like torch; training == 0: the running statistics normalise.  coef [4][C] (a, b, mean, invstd) is written by
- * the forward and read by the backward; y in the backward is the forward's output (ReLU mask; ignored when relu == 0). */
+ * the forward and read by the backward; y in the backward is the forward's output (ReLU mask; ignored when relu == 0) -- NULL when the
+ * forward had no residual: the mask is then recomputed as fmaf(x, a, b) > 0, the forward's own expression (one array less to read). */
 size_t hyb_bn2d_workspace(long long P, int C);
 int hyb_bn2d_fwd(const float* x, const float* gamma, const float* beta, const float* residual /* or NULL */, float* y, float* coef,
                  float* running_mean, float* running_var, long long P, int C, float eps, float momentum, int training, int relu,

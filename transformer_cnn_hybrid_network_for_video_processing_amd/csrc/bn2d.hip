@@ -104,19 +104,26 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict
 }
 
 // backward pass 1: part [block][2][C] doubles = sum dz, sum dz * xhat
-template <bool RELU>
+// RELU: 0 = none, 1 = mask from the forward output y (needed when a residual was added before the ReLU), 2 = mask recomputed from x
+// with the forward's own fmaf(x, a, b) > 0 (bit-identical decision, and one array less to read in both backward passes)
+template <int RELU>
 __global__ __launch_bounds__(256) void bn2d_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ coef, double* __restrict__ part, long long quads, int C) {
     __shared__ double red[256][8];
     const int CQ = C >> 2;
     const int tid = threadIdx.x, cq = tid % CQ;
     const float4 mean = ((const float4*)(coef + 2 * C))[cq], inv = ((const float4*)(coef + 3 * C))[cq];
+    const float4 ca = ((const float4*)coef)[cq], cb = ((const float4*)(coef + C))[cq];
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + tid; i < quads; i += stride) {
         float4 g = ((const float4*)dy)[i];
         const float4 v = ((const float4*)x)[i];
-        if (RELU) { const float4 o = ((const float4*)y)[i]; g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }
+        if (RELU == 1) { const float4 o = ((const float4*)y)[i]; g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }
+        if (RELU == 2) {
+            g.x = fmaf(v.x, ca.x, cb.x) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ca.y, cb.y) > 0.f ? g.y : 0.f;
+            g.z = fmaf(v.z, ca.z, cb.z) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ca.w, cb.w) > 0.f ? g.w : 0.f;
+        }
         s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
         q[0] = fma((double)g.x, (double)((v.x - mean.x) * inv.x), q[0]); q[1] = fma((double)g.y, (double)((v.y - mean.y) * inv.y), q[1]);
         q[2] = fma((double)g.z, (double)((v.z - mean.z) * inv.z), q[2]); q[3] = fma((double)g.w, (double)((v.w - mean.w) * inv.w), q[3]);
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64) void bn2d_bwd_finalize_kernel(const double* __r
     bcoef[2 * C + c] = training ? (float)(q / (double)P) : 0.f;
 }
 
-template <bool RELU, bool RES>
+template <int RELU, bool RES>
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ coef, const float* __restrict__ bcoef, float* __restrict__ dx,
                                                              float* __restrict__ dres, long long quads, int C) {
@@ -159,11 +166,16 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
     const int cq = threadIdx.x % CQ;
     const float4 mean = ((const float4*)(coef + 2 * C))[cq], inv = ((const float4*)(coef + 3 * C))[cq];
     const float4 k1 = ((const float4*)bcoef)[cq], k2 = ((const float4*)(bcoef + C))[cq], k3 = ((const float4*)(bcoef + 2 * C))[cq];
+    const float4 ca = ((const float4*)coef)[cq], cb = ((const float4*)(coef + C))[cq];
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += stride) {
         float4 g = ((const float4*)dy)[i];
         const float4 v = ((const float4*)x)[i];
-        if (RELU) { const float4 o = ((const float4*)y)[i]; g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }
+        if (RELU == 1) { const float4 o = ((const float4*)y)[i]; g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f; }
+        if (RELU == 2) {
+            g.x = fmaf(v.x, ca.x, cb.x) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, ca.y, cb.y) > 0.f ? g.y : 0.f;
+            g.z = fmaf(v.z, ca.z, cb.z) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, ca.w, cb.w) > 0.f ? g.w : 0.f;
+        }
         if (RES) ((float4*)dres)[i] = g;
         float4 o;
         o.x = k1.x * (g.x - k2.x - (v.x - mean.x) * inv.x * k3.x);
@@ -224,11 +236,12 @@ extern "C" int hyb_bn2d_fwd(const float* x, const float* gamma, const float* bet
     return 0;
 }
 
-// dresidual (nullable) receives the gradient of the fused residual input; y is the forward OUTPUT (ReLU mask; ignored when relu == 0)
+// dresidual (nullable) receives the gradient of the fused residual input; y is the forward OUTPUT (ReLU mask) -- pass NULL when no residual
+// was fused: the mask is then recomputed from x (ignored when relu == 0)
 extern "C" int hyb_bn2d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* coef, float* dx, float* dresidual,
                             float* dgamma, float* dbeta, long long P, int C, int training, int relu, void* workspace, size_t workspace_bytes,
                             void* stream) {
-    HYB_CHECK_ARG(dy && x && gamma && coef && dx && dgamma && dbeta && workspace && bn_shape_ok(P, C) && (!relu || y));
+    HYB_CHECK_ARG(dy && x && gamma && coef && dx && dgamma && dbeta && workspace && bn_shape_ok(P, C) && (!dresidual || !relu || y));
     if (workspace_bytes < hyb_bn2d_workspace(P, C)) return HYB_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const long long quads = P * (C / 4);
@@ -236,16 +249,19 @@ extern "C" int hyb_bn2d_bwd(const float* dy, const float* x, const float* y, con
     double* part = (double*)workspace;
     float* bcoef = (float*)((char*)workspace + al256((size_t)blocks * 2 * C * 8));
     const dim3 grid(blocks), blk(256);
-    if (relu) hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<true>, grid, blk, 0, st, dy, x, y, coef, part, quads, C);
-    else hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<false>, grid, blk, 0, st, dy, x, y, coef, part, quads, C);
+    // a ReLU without a fused residual (the caller passes y = NULL): y > 0 <=> fmaf(x, a, b) > 0, the forward's own expression
+    if (relu && y) hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<1>, grid, blk, 0, st, dy, x, y, coef, part, quads, C);
+    else if (relu) hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<2>, grid, blk, 0, st, dy, x, y, coef, part, quads, C);
+    else hipLaunchKernelGGL(bn2d_bwd_reduce_kernel<0>, grid, blk, 0, st, dy, x, y, coef, part, quads, C);
     HYB_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, (const double*)part, blocks, P, C, gamma, coef, training,
                        dgamma, dbeta, bcoef);
     HYB_LAUNCH_CHECK();
-    if (relu && dresidual) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<true, true>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
-    else if (relu) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<true, false>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
-    else if (dresidual) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<false, true>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
-    else hipLaunchKernelGGL((bn2d_bwd_apply_kernel<false, false>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
+    if (relu && y && dresidual) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<1, true>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
+    else if (relu && y) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<1, false>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
+    else if (relu) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<2, false>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
+    else if (dresidual) hipLaunchKernelGGL((bn2d_bwd_apply_kernel<0, true>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
+    else hipLaunchKernelGGL((bn2d_bwd_apply_kernel<0, false>), grid, blk, 0, st, dy, x, y, coef, (const float*)bcoef, dx, dresidual, quads, C);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -1630,7 +1630,7 @@ def bn2d_bwd_op(dy: Tensor, x: Tensor, y: Tensor, weight: Tensor, coef: Tensor, 
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = _ws(_query("hyb_bn2d_workspace", P, C), x.device)
-    lib.call("hyb_bn2d_bwd", dy.data_ptr(), x.data_ptr(), y.data_ptr() if relu else None, _f32c(weight).data_ptr(), coef.data_ptr(), dx.data_ptr(),
+    lib.call("hyb_bn2d_bwd", dy.data_ptr(), x.data_ptr(), y.data_ptr() if (relu and has_residual) else None, _f32c(weight).data_ptr(), coef.data_ptr(), dx.data_ptr(),
              dres.data_ptr() if has_residual else None, dg.data_ptr(), db.data_ptr(), P, C, int(training), int(relu), ws.data_ptr(), ws.numel(),
              _stream())
     return dx, dres, dg, db
@@ -1647,7 +1647,7 @@ class _Bn2dFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         with _below_autograd():
             y, coef = torch.ops.hybrid.bn2d(x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu)
-        ctx.save_for_backward(x, weight, coef, y if relu else _e0(x))
+        ctx.save_for_backward(x, weight, coef, y if (relu and residual is not None) else _e0(x))     # without a residual the mask is recomputed from x
         ctx.cfg = (training, relu, residual is not None)
         ctx.mark_non_differentiable(coef)
         return y, coef
