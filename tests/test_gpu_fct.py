@@ -117,10 +117,11 @@ def test_qkv_projection_and_layernorm(c, n, h, w):
     assert rel(nchw(xg.grad), x2.grad) <= 1e-4 and rel(wg.grad, ln.weight.grad) <= 1e-4 and rel(bg.grad, ln.bias.grad) <= 1e-4
 
 
-# (.., 1024 / 1100 / 1283 / 1029, 8, 2): heads of 4 features with >= 1024 tokens take the 4x4x1-MFMA kernels (a query / key per lane);
+# (.., 1024 / 1100 / 1283 / 1029, 8, 2) and (.., 4096 / 1100 / 1027, 16, 2): heads of 4 and of 8 features with >= 1024 tokens take the 4x4x1-MFMA
+# kernels (a query / key per lane; one or two feature quads);
 # 1100, 1283 and 1029 are not multiples of 16 or 256: ragged key groups, padding queries, a partial last workgroup
 @pytest.mark.parametrize("n,l,c,heads", [(2, 64, 8, 2), (1, 100, 16, 2), (2, 1024, 8, 2), (1, 257, 64, 2), (1, 49, 128, 2), (3, 16, 32, 4), (1, 4096, 16, 2),
-                                         (1, 1100, 8, 2), (2, 1283, 8, 2), (1, 1029, 8, 2)])
+                                         (1, 1100, 8, 2), (2, 1283, 8, 2), (1, 1029, 8, 2), (1, 1100, 16, 2), (2, 1027, 16, 2)])
 def test_multihead_attention_over_pixel_tokens(n, l, c, heads):
     torch.manual_seed(l + c)
     mha = torch.nn.MultiheadAttention(c, heads, batch_first=True)

@@ -690,56 +690,78 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int F4_KB = 256, F4_VLD = F4_KB + 4;
 constexpr float F4_LAZY = 12.f;           // the exponent's reference point moves when a score exceeds it by more than 2^12 (fp32 sums: far from overflow)
+// NF = feature quads per head: 1 for heads of <= 4 features (12 544 tokens), 2 for heads of 5..8 (3 136 tokens); the padded head width is 8.
+template <int NF>
 __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             float* __restrict__ out, float* __restrict__ lse, int L, int H, int ld,
                                                             float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) float Kimg[F4_KB * 4];        // [key][feature]
-    __shared__ __attribute__((aligned(16))) float Vt[4 * F4_VLD];         // [feature][key]
+    constexpr int FW = 4 * NF;
+    __shared__ __attribute__((aligned(16))) float Kimg[F4_KB * FW];       // [key][feature]
+    __shared__ __attribute__((aligned(16))) float Vt[FW * F4_VLD];        // [feature][key]
     const int tid = threadIdx.x, j4 = tid & 3;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * 8;                 // padded head width 8
     const int query = blockIdx.x * 256 + tid;
     const int qrow = query < L ? query : L - 1;
-    f32x4 qv = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld);
-    qv *= scale_log2e;                                                     // scores come out in log2 units: exp2 below
+    f32x4 qv[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) { qv[nf] = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld + 4 * nf); qv[nf] *= scale_log2e; }
     // LAZY RESCALING.  m is a per-lane reference point of the exponent, not the running maximum: the score accumulators START at -m, so
     // the matrix instruction delivers s - m and p = exp2(s - m) needs no subtraction; m moves (with the usual rescale of l and o) only
     // when some score exceeds it by more than 2^F4_LAZY -- after the first keys that is rare, and the test is one wave-uniform branch.
     // softmax is shift-invariant, so the result is the same function; lse = m ln2 + ln(l) stays exact.  m starts at the score of key 0.
     float l = 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) o[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m;
-    {
-        const f32x4 k0v = *reinterpret_cast<const f32x4*>(k + base);
-        m = (qv[0] * k0v[0] + qv[1] * k0v[1]) + (qv[2] * k0v[2] + qv[3] * k0v[3]);
+    f32x4 o[NF][4];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[nf][g] = zero4;
+    float m = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const f32x4 k0v = *reinterpret_cast<const f32x4*>(k + base + 4 * nf);
+        m += (qv[nf][0] * k0v[0] + qv[nf][1] * k0v[1]) + (qv[nf][2] * k0v[2] + qv[nf][3] * k0v[3]);
     }
-    f32x4 kr = zero4, vr = zero4;
-    if (tid < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld); }
+    f32x4 kr[NF], vr[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        kr[nf] = zero4; vr[nf] = zero4;
+        if (tid < L) { kr[nf] = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld + 4 * nf); vr[nf] = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld + 4 * nf); }
+    }
     for (int kb = 0; kb < L; kb += F4_KB) {
         __syncthreads();                                                   // every wave is done with the previous block's images
-        *reinterpret_cast<f32x4*>(Kimg + tid * 4) = kr;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) Vt[f * F4_VLD + tid] = vr[f];
+        for (int nf = 0; nf < NF; ++nf) {
+            *reinterpret_cast<f32x4*>(Kimg + tid * FW + 4 * nf) = kr[nf];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) Vt[(4 * nf + f) * F4_VLD + tid] = vr[nf][f];
+        }
         __syncthreads();
         {
             const int nx = kb + F4_KB + tid;                               // the next block's row of this thread: in flight during the block
-            kr = zero4; vr = zero4;
-            if (nx < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld); }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                kr[nf] = zero4; vr[nf] = zero4;
+                if (nx < L) { kr[nf] = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld + 4 * nf); vr[nf] = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld + 4 * nf); }
+            }
         }
         const int nk = L - kb < F4_KB ? L - kb : F4_KB;
         for (int k0 = 0; k0 < nk; k0 += 16) {
             f32x4 s[4];
-            f32x4 kk[4];
             const f32x4 nm4 = f32x4{-m, -m, -m, -m};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { kk[g] = *reinterpret_cast<const f32x4*>(Kimg + (k0 + 4 * g + j4) * 4); s[g] = nm4; }
+            for (int g = 0; g < 4; ++g) s[g] = nm4;
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 kk[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[f], s[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) kk[g] = *reinterpret_cast<const f32x4*>(Kimg + (k0 + 4 * g + j4) * FW + 4 * nf);
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[nf][f], s[g], 0, 0, 0);
+            }
             if (k0 + 16 > nk) {                                            // ragged tail of the last block (uniform branch)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -756,7 +778,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
                 l *= alpha;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    o[g] *= alpha;
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) o[nf][g] *= alpha;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[g][r] -= d;
                 }
@@ -767,78 +790,105 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s[g][r] = __builtin_amdgcn_exp2f(s[g][r]); sum += s[g][r]; }
             l += sum;
-            f32x4 vv[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) vv[g] = *reinterpret_cast<const f32x4*>(Vt + j4 * F4_VLD + k0 + 4 * g);
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 vv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int g = 0; g < 4; ++g) vv[g] = *reinterpret_cast<const f32x4*>(Vt + (4 * nf + j4) * F4_VLD + k0 + 4 * g);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) o[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][i], s[g][i], o[g], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) o[nf][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][i], s[g][i], o[nf][g], 0, 0, 0);
+            }
         }
     }
     if (query >= L) return;
-    const f32x4 ot = ((o[0] + o[1]) + (o[2] + o[3])) * (1.f / l);
+    const float inv = 1.f / l;
     float* dst = out + base + (long long)query * ld;
-    *reinterpret_cast<f32x4*>(dst) = ot;
-    *reinterpret_cast<f32x4*>(dst + 4) = zero4;                            // the padded features of the head
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) *reinterpret_cast<f32x4*>(dst + 4 * nf) = ((o[nf][0] + o[nf][1]) + (o[nf][2] + o[nf][3])) * inv;
+    if (NF == 1) *reinterpret_cast<f32x4*>(dst + 4) = zero4;               // the padded features of the head
     if (lse) lse[(long long)blockIdx.y * L + query] = m * 0.6931471805599453f + __logf(l);     // natural-log sum-exp of the scaled scores
 }
 
 // Backward of the same heads, the same way.  dQ kernel: a lane owns a QUERY and walks the keys (256-key blocks in LDS: K rows, K columns,
-// V rows): per 4 keys 4 instructions give its scores, 4 its dP = dO . V, the softmax backward dS = P (dP - delta) scale is per-lane
-// arithmetic (the row's log-sum-exp and delta are the lane's own scalars), 4 instructions accumulate dQ += dS K.
+// V rows): per 4 keys 4 NF instructions give its scores, 4 NF its dP = dO . V, the softmax backward dS = P (dP - delta) scale is per-lane
+// arithmetic (the row's log-sum-exp and delta are the lane's own scalars), 4 NF instructions accumulate dQ += dS K.
+template <int NF>
 __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, float* __restrict__ dq, int L, int H, int ld,
                                                                float scale) {
-    __shared__ __attribute__((aligned(16))) float Kr[F4_KB * 4];          // [key][feature]
-    __shared__ __attribute__((aligned(16))) float Vr[F4_KB * 4];
-    __shared__ __attribute__((aligned(16))) float Kt[4 * F4_VLD];         // [feature][key]
+    constexpr int FW = 4 * NF;
+    __shared__ __attribute__((aligned(16))) float Kr[F4_KB * FW];         // [key][feature]
+    __shared__ __attribute__((aligned(16))) float Vr[F4_KB * FW];
+    __shared__ __attribute__((aligned(16))) float Kt[FW * F4_VLD];        // [feature][key]
     const int tid = threadIdx.x, j4 = tid & 3;
     const int n = blockIdx.y / H, h = blockIdx.y - n * H;
     const long long base = (long long)n * L * ld + h * 8;
     const int query = blockIdx.x * 256 + tid;
     const int qrow = query < L ? query : L - 1;
     const float LOG2E = 1.4426950408889634f;
-    f32x4 qv = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld);
-    qv *= scale * LOG2E;
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(dout + base + (long long)qrow * ld);
+    f32x4 qv[NF], gv[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        qv[nf] = *reinterpret_cast<const f32x4*>(q + base + (long long)qrow * ld + 4 * nf);
+        qv[nf] *= scale * LOG2E;
+        gv[nf] = *reinterpret_cast<const f32x4*>(dout + base + (long long)qrow * ld + 4 * nf);
+    }
     const float lse2 = lse[(long long)blockIdx.y * L + qrow] * LOG2E, dl = delta[(long long)blockIdx.y * L + qrow];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 nlse4 = f32x4{-lse2, -lse2, -lse2, -lse2}, ndl4 = f32x4{-dl, -dl, -dl, -dl};
-    f32x4 acc[4];
+    f32x4 acc[NF][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = zero4;
-    f32x4 kr = zero4, vr = zero4;
-    if (tid < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld); }
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[nf][g] = zero4;
+    f32x4 kr[NF], vr[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        kr[nf] = zero4; vr[nf] = zero4;
+        if (tid < L) { kr[nf] = *reinterpret_cast<const f32x4*>(k + base + (long long)tid * ld + 4 * nf); vr[nf] = *reinterpret_cast<const f32x4*>(v + base + (long long)tid * ld + 4 * nf); }
+    }
     for (int kb = 0; kb < L; kb += F4_KB) {
         __syncthreads();
-        *reinterpret_cast<f32x4*>(Kr + tid * 4) = kr;
-        *reinterpret_cast<f32x4*>(Vr + tid * 4) = vr;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) Kt[f * F4_VLD + tid] = kr[f];
+        for (int nf = 0; nf < NF; ++nf) {
+            *reinterpret_cast<f32x4*>(Kr + tid * FW + 4 * nf) = kr[nf];
+            *reinterpret_cast<f32x4*>(Vr + tid * FW + 4 * nf) = vr[nf];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) Kt[(4 * nf + f) * F4_VLD + tid] = kr[nf][f];
+        }
         __syncthreads();
         {
             const int nx = kb + F4_KB + tid;
-            kr = zero4; vr = zero4;
-            if (nx < L) { kr = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld); vr = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld); }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                kr[nf] = zero4; vr[nf] = zero4;
+                if (nx < L) { kr[nf] = *reinterpret_cast<const f32x4*>(k + base + (long long)nx * ld + 4 * nf); vr[nf] = *reinterpret_cast<const f32x4*>(v + base + (long long)nx * ld + 4 * nf); }
+            }
         }
         const int nk = L - kb < F4_KB ? L - kb : F4_KB;
         for (int k0 = 0; k0 < nk; k0 += 16) {
-            f32x4 s[4], dp[4], kk[4], vv[4];
+            f32x4 s[4], dp[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                kk[g] = *reinterpret_cast<const f32x4*>(Kr + (k0 + 4 * g + j4) * 4);
-                vv[g] = *reinterpret_cast<const f32x4*>(Vr + (k0 + 4 * g + j4) * 4);
-                s[g] = nlse4; dp[g] = ndl4;                               // the accumulators start at -lse and -delta: the subtractions are free
-            }
+            for (int g = 0; g < 4; ++g) { s[g] = nlse4; dp[g] = ndl4; }  // the accumulators start at -lse and -delta: the subtractions are free
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 kk[4], vv[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[f], s[g], 0, 0, 0);
-                    dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][f], gv[f], dp[g], 0, 0, 0);
+                    kk[g] = *reinterpret_cast<const f32x4*>(Kr + (k0 + 4 * g + j4) * FW + 4 * nf);
+                    vv[g] = *reinterpret_cast<const f32x4*>(Vr + (k0 + 4 * g + j4) * FW + 4 * nf);
                 }
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kk[g][f], qv[nf][f], s[g], 0, 0, 0);
+                        dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv[g][f], gv[nf][f], dp[g], 0, 0, 0);
+                    }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -849,32 +899,38 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dq_kernel(const float* __re
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (k0 + 4 * g + r >= nk) s[g][r] = 0.f;
             }
-            f32x4 kt[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) kt[g] = *reinterpret_cast<const f32x4*>(Kt + j4 * F4_VLD + k0 + 4 * g);
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 kt[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int g = 0; g < 4; ++g) kt[g] = *reinterpret_cast<const f32x4*>(Kt + (4 * nf + j4) * F4_VLD + k0 + 4 * g);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kt[g][i], s[g][i], acc[g], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[nf][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(kt[g][i], s[g][i], acc[nf][g], 0, 0, 0);
+            }
         }
     }
     if (query >= L) return;
     float* dst = dq + base + (long long)query * ld;
-    *reinterpret_cast<f32x4*>(dst) = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * scale;
-    *reinterpret_cast<f32x4*>(dst + 4) = zero4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) *reinterpret_cast<f32x4*>(dst + 4 * nf) = ((acc[nf][0] + acc[nf][1]) + (acc[nf][2] + acc[nf][3])) * scale;
+    if (NF == 1) *reinterpret_cast<f32x4*>(dst + 4) = zero4;
 }
 
 // dK / dV kernel: a lane owns a KEY and walks the queries (256-query blocks in LDS: q and dO as rows and as columns, the rows' log-sum-exp
-// and delta): per 4 queries 4 instructions give S^T, 4 give dP^T, then dV += P^T dO and dK += dS^T Q with 4 instructions each.  Queries
-// past the sequence are staged with lse = +inf: their probabilities are exactly 0, no tail branch.
+// and delta): per 4 queries 4 NF instructions give S^T, 4 NF give dP^T, then dV += P^T dO and dK += dS^T Q with 4 NF instructions each.
+// Queries past the sequence are staged with lse = +inf: their probabilities are exactly 0, no tail branch.
+template <int NF>
 __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                                 const float* __restrict__ dout, const float* __restrict__ lse,
                                                                 const float* __restrict__ delta, float* __restrict__ dk, float* __restrict__ dv, int L,
                                                                 int H, int ld, float scale) {
-    __shared__ __attribute__((aligned(16))) float Qr[F4_KB * 4];          // [query][feature]
-    __shared__ __attribute__((aligned(16))) float Gr[F4_KB * 4];
-    __shared__ __attribute__((aligned(16))) float Qt[4 * F4_VLD];         // [feature][query]
-    __shared__ __attribute__((aligned(16))) float Gt[4 * F4_VLD];
+    constexpr int FW = 4 * NF;
+    __shared__ __attribute__((aligned(16))) float Qr[F4_KB * FW];         // [query][feature]
+    __shared__ __attribute__((aligned(16))) float Gr[F4_KB * FW];
+    __shared__ __attribute__((aligned(16))) float Qt[FW * F4_VLD];        // [feature][query]
+    __shared__ __attribute__((aligned(16))) float Gt[FW * F4_VLD];
     __shared__ __attribute__((aligned(16))) float Ls[F4_KB];              // MINUS the log2-domain log-sum-exp per query
     __shared__ __attribute__((aligned(16))) float Ds[F4_KB];              // MINUS delta per query
     const int tid = threadIdx.x, j4 = tid & 3;
@@ -884,52 +940,72 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
     const int key = blockIdx.x * 256 + tid;
     const int krow = key < L ? key : L - 1;
     const float LOG2E = 1.4426950408889634f;
-    f32x4 ks = *reinterpret_cast<const f32x4*>(k + base + (long long)krow * ld);
-    ks *= scale * LOG2E;
-    const f32x4 vo = *reinterpret_cast<const f32x4*>(v + base + (long long)krow * ld);
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 adk[4], adv[4];
+    f32x4 ks[NF], vo[NF];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { adk[g] = zero4; adv[g] = zero4; }
-    f32x4 qr = zero4, gr = zero4;
-    float lr = INFINITY, dr = 0.f;
-    if (tid < L) {
-        qr = *reinterpret_cast<const f32x4*>(q + base + (long long)tid * ld); gr = *reinterpret_cast<const f32x4*>(dout + base + (long long)tid * ld);
-        lr = lse[sbase + tid] * LOG2E; dr = delta[sbase + tid];
+    for (int nf = 0; nf < NF; ++nf) {
+        ks[nf] = *reinterpret_cast<const f32x4*>(k + base + (long long)krow * ld + 4 * nf);
+        ks[nf] *= scale * LOG2E;
+        vo[nf] = *reinterpret_cast<const f32x4*>(v + base + (long long)krow * ld + 4 * nf);
     }
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 adk[NF][4], adv[NF][4];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { adk[nf][g] = zero4; adv[nf][g] = zero4; }
+    f32x4 qr[NF], gr[NF];
+    float lr = INFINITY, dr = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        qr[nf] = zero4; gr[nf] = zero4;
+        if (tid < L) { qr[nf] = *reinterpret_cast<const f32x4*>(q + base + (long long)tid * ld + 4 * nf); gr[nf] = *reinterpret_cast<const f32x4*>(dout + base + (long long)tid * ld + 4 * nf); }
+    }
+    if (tid < L) { lr = lse[sbase + tid] * LOG2E; dr = delta[sbase + tid]; }
     for (int qb = 0; qb < L; qb += F4_KB) {
         __syncthreads();
-        *reinterpret_cast<f32x4*>(Qr + tid * 4) = qr;
-        *reinterpret_cast<f32x4*>(Gr + tid * 4) = gr;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { Qt[f * F4_VLD + tid] = qr[f]; Gt[f * F4_VLD + tid] = gr[f]; }
+        for (int nf = 0; nf < NF; ++nf) {
+            *reinterpret_cast<f32x4*>(Qr + tid * FW + 4 * nf) = qr[nf];
+            *reinterpret_cast<f32x4*>(Gr + tid * FW + 4 * nf) = gr[nf];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { Qt[(4 * nf + f) * F4_VLD + tid] = qr[nf][f]; Gt[(4 * nf + f) * F4_VLD + tid] = gr[nf][f]; }
+        }
         Ls[tid] = -lr; Ds[tid] = -dr;
         __syncthreads();
         {
             const int nx = qb + F4_KB + tid;
-            qr = zero4; gr = zero4; lr = INFINITY; dr = 0.f;
-            if (nx < L) {
-                qr = *reinterpret_cast<const f32x4*>(q + base + (long long)nx * ld); gr = *reinterpret_cast<const f32x4*>(dout + base + (long long)nx * ld);
-                lr = lse[sbase + nx] * LOG2E; dr = delta[sbase + nx];
+            lr = INFINITY; dr = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                qr[nf] = zero4; gr[nf] = zero4;
+                if (nx < L) { qr[nf] = *reinterpret_cast<const f32x4*>(q + base + (long long)nx * ld + 4 * nf); gr[nf] = *reinterpret_cast<const f32x4*>(dout + base + (long long)nx * ld + 4 * nf); }
             }
+            if (nx < L) { lr = lse[sbase + nx] * LOG2E; dr = delta[sbase + nx]; }
         }
         const int nq = L - qb < F4_KB ? L - qb : F4_KB;
         for (int q0 = 0; q0 < nq; q0 += 16) {
-            f32x4 s[4], dp[4], qq[4], gg[4];
+            f32x4 s[4], dp[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                qq[g] = *reinterpret_cast<const f32x4*>(Qr + (q0 + 4 * g + j4) * 4);
-                gg[g] = *reinterpret_cast<const f32x4*>(Gr + (q0 + 4 * g + j4) * 4);
                 s[g] = *reinterpret_cast<const f32x4*>(Ls + q0 + 4 * g);        // accumulators start at -lse / -delta of the four queries
                 dp[g] = *reinterpret_cast<const f32x4*>(Ds + q0 + 4 * g);
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 qq[4], gg[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qq[g][f], ks[f], s[g], 0, 0, 0);
-                    dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gg[g][f], vo[f], dp[g], 0, 0, 0);
+                    qq[g] = *reinterpret_cast<const f32x4*>(Qr + (q0 + 4 * g + j4) * FW + 4 * nf);
+                    gg[g] = *reinterpret_cast<const f32x4*>(Gr + (q0 + 4 * g + j4) * FW + 4 * nf);
                 }
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qq[g][f], ks[nf][f], s[g], 0, 0, 0);
+                        dp[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gg[g][f], vo[nf][f], dp[g], 0, 0, 0);
+                    }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -938,28 +1014,33 @@ __global__ __launch_bounds__(256, 2) void flash_bwd4_dkv_kernel(const float* __r
                     s[g][r] = pv;
                     dp[g][r] *= pv;                                                    // (the factor `scale` is applied once, to dK)
                 }
-            f32x4 qt[4], gt[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                qt[g] = *reinterpret_cast<const f32x4*>(Qt + j4 * F4_VLD + q0 + 4 * g);
-                gt[g] = *reinterpret_cast<const f32x4*>(Gt + j4 * F4_VLD + q0 + 4 * g);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int nf = 0; nf < NF; ++nf) {
+                f32x4 qt[4], gt[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    adv[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gt[g][i], s[g][i], adv[g], 0, 0, 0);
-                    adk[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qt[g][i], dp[g][i], adk[g], 0, 0, 0);
+                    qt[g] = *reinterpret_cast<const f32x4*>(Qt + (4 * nf + j4) * F4_VLD + q0 + 4 * g);
+                    gt[g] = *reinterpret_cast<const f32x4*>(Gt + (4 * nf + j4) * F4_VLD + q0 + 4 * g);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        adv[nf][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(gt[g][i], s[g][i], adv[nf][g], 0, 0, 0);
+                        adk[nf][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(qt[g][i], dp[g][i], adk[nf][g], 0, 0, 0);
+                    }
+            }
         }
     }
     if (key >= L) return;
     float* dkd = dk + base + (long long)key * ld;
     float* dvd = dv + base + (long long)key * ld;
-    *reinterpret_cast<f32x4*>(dkd) = ((adk[0] + adk[1]) + (adk[2] + adk[3])) * scale;
-    *reinterpret_cast<f32x4*>(dkd + 4) = zero4;
-    *reinterpret_cast<f32x4*>(dvd) = (adv[0] + adv[1]) + (adv[2] + adv[3]);
-    *reinterpret_cast<f32x4*>(dvd + 4) = zero4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        *reinterpret_cast<f32x4*>(dkd + 4 * nf) = ((adk[nf][0] + adk[nf][1]) + (adk[nf][2] + adk[nf][3])) * scale;
+        *reinterpret_cast<f32x4*>(dvd + 4 * nf) = (adv[nf][0] + adv[nf][1]) + (adv[nf][2] + adv[nf][3]);
+    }
+    if (NF == 1) { *reinterpret_cast<f32x4*>(dkd + 4) = zero4; *reinterpret_cast<f32x4*>(dvd + 4) = zero4; }
 }
 
 // delta[nh][q] = sum_d dO[q][d] * O[q][d]  (the softmax-backward row term; one thread per (image, head, query))
@@ -1162,9 +1243,11 @@ int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void*
                             float scale, hipStream_t st, int dh_true) {
     if (!q || !k || !v || !out || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 || dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535) return HYB_E_ARG;
     static const int f4_env = getenv("HYB_FLASH_FWD4") ? atoi(getenv("HYB_FLASH_FWD4")) : 1;
-    if (dtype == HYB_F32 && f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 4 && L >= 1024) {
-        // heads of <= 4 features: the 4x4x1 matrix instruction, a query per lane (features 4..7 of q, k, v are the zero padding)
-        hipLaunchKernelGGL(flash_fwd4_kernel, dim3(hyb_cdiv(L, 256), N * H), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
+    if (dtype == HYB_F32 && f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 8 && L >= 1024) {
+        // heads of <= 8 features: the 4x4x1 matrix instruction, a query per lane (for <= 4 features the quad 4..7 of q, k, v is zero padding)
+        if (dh_true <= 4) hipLaunchKernelGGL(flash_fwd4_kernel<1>, dim3(hyb_cdiv(L, 256), N * H), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
+                                             (float*)out, lse, L, H, ld, scale * 1.4426950408889634f);
+        else hipLaunchKernelGGL(flash_fwd4_kernel<2>, dim3(hyb_cdiv(L, 256), N * H), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
                            (float*)out, lse, L, H, ld, scale * 1.4426950408889634f);
         HYB_LAUNCH_CHECK();
         return 0;
@@ -1200,12 +1283,19 @@ int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void*
     const long long nq = (long long)N * H * L;
     hipLaunchKernelGGL(flash_delta_kernel<float>, dim3(hyb_cdiv(nq, 256)), dim3(256), 0, st, (const float*)o, (const float*)dout, delta_ws, N, L, H, dhp, ld);
     static const int f4_env = getenv("HYB_FLASH_BWD4") ? atoi(getenv("HYB_FLASH_BWD4")) : 1;
-    if (f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 4 && L >= 1024) {      // heads of <= 4 features: the 4x4x1 matrix instruction
+    if (f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 8 && L >= 1024) {      // heads of <= 8 features: the 4x4x1 matrix instruction
         const dim3 grid4(hyb_cdiv(L, 256), N * H);
-        hipLaunchKernelGGL(flash_bwd4_dq_kernel, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
-                           (const float*)delta_ws, (float*)dq, L, H, ld, scale);
-        hipLaunchKernelGGL(flash_bwd4_dkv_kernel, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
-                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
+        if (dh_true <= 4) {
+            hipLaunchKernelGGL(flash_bwd4_dq_kernel<1>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                               (const float*)delta_ws, (float*)dq, L, H, ld, scale);
+            hipLaunchKernelGGL(flash_bwd4_dkv_kernel<1>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                               (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
+        } else {
+            hipLaunchKernelGGL(flash_bwd4_dq_kernel<2>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                               (const float*)delta_ws, (float*)dq, L, H, ld, scale);
+            hipLaunchKernelGGL(flash_bwd4_dkv_kernel<2>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
+                               (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
+        }
         HYB_LAUNCH_CHECK();
         return 0;
     }
