@@ -118,7 +118,10 @@ constexpr int MAXDT = 8;      // head width <= 128
 template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
                                      T* __restrict__ out, float* __restrict__ stats, AttnDims d, float scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
-    if (seed_inc) seed += *seed_inc;                            // device-side step counter (captured launches draw a fresh mask per replay)
+    // device-side step counter (captured launches draw a fresh mask per replay): requested here, consumed after the V image barrier, so the
+    // scalar round trip overlaps the staging loads instead of preceding everything
+    unsigned long long seed_step = 0;
+    if (p_drop > 0.f && seed_inc) seed_step = *seed_inc;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NTC = SINGLE ? 1 : MAXT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(cons
 
     stage_image(Vimg, v, d, b, h, d.ld_qkv, multi ? lane : tid, multi ? 64 : (int)blockDim.x);
     __syncthreads();                                           // V image complete
+    seed += seed_step;
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   for (int qt = wave; qt < d.nt; qt += nw) {
     // S^T tiles: rows = keys of tile kt, columns = this tile's 16 queries
@@ -223,7 +227,8 @@ template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ mask,
                                      const float* __restrict__ stats, const T* __restrict__ dout, T* __restrict__ dq, T* __restrict__ dk,
                                      T* __restrict__ dv, AttnDims d, float scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
-    if (seed_inc) seed += *seed_inc;                            // device-side step counter (captured launches draw a fresh mask per replay)
+    unsigned long long seed_step = 0;                           // device-side step counter: requested here, consumed after the image barrier
+    if (p_drop > 0.f && seed_inc) seed_step = *seed_inc;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NTC = SINGLE ? 1 : MAXT;
     const int rows = d.nt * 16;
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         stage_image(Gimg, dout, d, b, h, d.ld_o, pt, pn);
     }
     __syncthreads();                                           // images complete
+    seed += seed_step;
     // single-tile sequences (S <= 16): the row fragments of K, Q, V, dO are the same registers in both phases (A and B operands
     // of the 16x16x32 MFMA have the same lane layout), so they are loaded once
     Frag<T> fk[SINGLE ? 4 : 1], fq[SINGLE ? 4 : 1], fv[SINGLE ? 4 : 1], fg[SINGLE ? 4 : 1];
