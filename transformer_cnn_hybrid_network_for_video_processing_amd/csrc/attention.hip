@@ -774,9 +774,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (k0 + 4 * g + r >= nk) s[g][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+            float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), s[0][3]);                 // chains of three: v_max3_f32 (8 instead of 15)
 #pragma unroll
-            for (int g = 1; g < 4; ++g) mx = fmaxf(fmaxf(mx, fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
+            for (int g = 1; g < 4; ++g) mx = fmaxf(fmaxf(mx, fmaxf(fmaxf(s[g][0], s[g][1]), s[g][2])), s[g][3]);
             if (__builtin_amdgcn_ballot_w64(mx > F4_LAZY) != 0ull) {       // rare after the first keys: move the reference of the lanes that need it
                 const float d = mx > F4_LAZY ? mx : 0.f;
                 const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -790,12 +790,14 @@ __global__ __launch_bounds__(256, 2) void flash_fwd4_kernel(const float* __restr
                     for (int r = 0; r < 4; ++r) s[g][r] -= d;
                 }
             }
-            float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[g][r] = __builtin_amdgcn_exp2f(s[g][r]); sum += s[g][r]; }
-            l += sum;
+                for (int r = 0; r < 4; ++r) s[g][r] = __builtin_amdgcn_exp2f(s[g][r]);
+            {
+                const f32x4 t4 = (s[0] + s[1]) + (s[2] + s[3]);            // packed adds
+                l += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            }
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 f32x4 vv[4];
