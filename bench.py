@@ -213,7 +213,9 @@ def instep_kernel_table(args, step_fn, nsteps=8):
         specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_v2_kernel", flops, io))
         # the wgrad kernel is fused with the BN/ReLU/pool backward: reads x, raw conv output y, dpooled; writes the dense gradient + dW
         io_w = float(N * H * H * (ci + 2 * co) * 2 + N * (H // 2) * (H // 2) * co * 2)
-        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v2_kernel<true, %d>" % (64 if ci % 64 == 0 else 32), flops, io_w))
+        # (kernel names as rocprofv3 lists them: the third-generation kernel takes 64-channel blocks on images of 28 k columns, conv_wgrad_v3.h)
+        gen3 = ci % 64 == 0 and co % 64 == 0 and H % 28 == 0 and H % 4 == 0 and os.environ.get("HYB_WGRAD_V3", "1") != "0"
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v3_kernel" if gen3 else "wgrad_v2_kernel<true, %d>" % (64 if ci % 64 == 0 else 32), flops, io_w))
         H //= 2
     evs = []
     for slot, sp in enumerate(specs):
@@ -495,7 +497,7 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             traffic, tsrc = None, None
-            for tname in ("r02_traffic.json", "r01_traffic.json"):           # PMC bytes per launch (rocprofv3 --pmc passes of this command)
+            for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):           # PMC bytes per launch (rocprofv3 --pmc passes of this command)
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and args.dtype == "bf16" and args.config == 2 and is_cfg:
                     t = json.load(open(tpath)).get(dom["name"])

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../.."
 PKG=transformer_cnn_hybrid_network_for_video_processing_amd
 OUT=scripts/micro/wg
 mkdir -p $OUT
-HF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc -Wno-unused-result"
+HF="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc -Iscripts/micro/wgrad_variants -DHYB_WGRAD_EXPERIMENTS -fno-slp-vectorize -Wno-unused-result"
 hipcc $HF -c scripts/micro/wgrad_stub.hip -o $OUT/stub.o &
 hipcc -O2 -std=c++17 scripts/micro/wgrad_bench.cpp -o $OUT/wgrad_bench -ldl &
 for v in "$@"; do

@@ -24,7 +24,7 @@ for k in sorted(fe, key=lambda k: -sum(fe[k])):
     fb, wb = f_avg * 1024 * 2, w_avg * 1024
     rows.append((short(k), len(fe[k]), round(f_avg), round(fb), round(w_avg), round(fb + wb)))
     m = re.search(r"wgrad_v2_kernel<(true|false), (\d+)[,>]", k) if ("wgrad" in k and "reduce" not in k) else None
-    name = "wgrad_v2_kernel<%s, %s>" % (m.group(1), m.group(2)) if m else short(k)
+    name = "wgrad_v2_kernel<%s, %s>" % (m.group(1), m.group(2)) if m else ("wgrad_v3_kernel" if "wgrad_v3_kernel" in k else short(k))
     if name not in traffic:
         traffic[name] = {"hbm_bytes_per_launch": fb + wb, "fetch_size_kb_raw_avg": f_avg, "write_size_kb_avg": w_avg, "launches_sampled": len(fe[k]),
                          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --eager --steps 6 "

@@ -10,6 +10,7 @@
 // walks a strided subset of 8x16-pixel tiles; partial blocks go to fp32 slabs [S][Cop][9][Cip] that a
 // second kernel sums in a fixed order (bitwise reproducible; no float atomics).
 #include <stdlib.h>
+#include <type_traits>
 #include "hyb_common.h"
 
 namespace {
@@ -656,6 +657,10 @@ int w2_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, co
 }
 
 #include "conv_wgrad_v3.h"
+#ifdef HYB_WGRAD_EXPERIMENTS      // scripts/micro/wgrad_variants: the 16-wave and the pipelined 12-wave forms measured in round 3 (not faster)
+#include "conv_wgrad_v4.h"
+#include "conv_wgrad_v5.h"
+#endif
 
 // few slabs (second-generation kernel: S = 256 / blocks): one thread per output element walks the S slabs; loads are issued
 // eight at a time, the additions keep the slab order
@@ -702,7 +707,9 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
         const int ci_blk = Cip % 64 == 0 ? 64 : 32;
         const int blocks = (Cop / 64) * (Cip / ci_blk);
         if (v2 && !first && Cip % 32 == 0 && Cop % 64 == 0 && blocks <= 256 && (long long)12 * W * (Cip > Cop ? Cip : Cop) < (1ll << 29)) {
-            const int tX = hyb_cdiv(W, W2_TW), tY = hyb_cdiv(H, W2_TH);
+            // generation of the fused kernel for this shape: 0 second (below), 1 third (conv_wgrad_v3.h); 2 / 3 only in experiment builds
+            const int gen3 = (fz && ci_blk == 64) ? w3_supported(H, W, Cip, Cop) : 0;
+            const int tX = hyb_cdiv(W, W2_TW), tY = gen3 == 3 ? H / 4 : hyb_cdiv(H, W2_TH);
             const long long nT = (long long)N * tX * tY;
             int S = 256 / blocks;
             if (S > p.S) S = p.S;                          // never more slabs than the workspace query promised
@@ -712,8 +719,12 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
             const WgradFuse fzv = fz ? *fz : WgradFuse{};
             const dim3 grid2(S, blocks);
             int lrc = 0;
-            if (fz && ci_blk == 64 && w3_supported(H, W, Cip, Cop))
-                lrc = w3_launch(grid2, hook2, st, (const bf16*)x, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
+#ifdef HYB_WGRAD_EXPERIMENTS
+            if (gen3 == 3) lrc = w5_launch(grid2, hook2, st, (const bf16*)x, slab, N, H, W, Cip, Cop, (int)nT, fzv);
+            else if (gen3 == 2) lrc = w4_launch(grid2, hook2, st, (const bf16*)x, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
+            else
+#endif
+            if (gen3) lrc = w3_launch(grid2, hook2, st, (const bf16*)x, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
             else if (ci_blk == 64) lrc = fz ? w2_launch<true, 64>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv)
                                        : w2_launch<false, 64>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv);
             else lrc = fz ? w2_launch<true, 32>(grid2, hook2, st, (const bf16*)x, (const bf16*)dy, slab, N, H, W, Cip, Cop, tX, tY, (int)nT, fzv)

@@ -25,11 +25,11 @@ constexpr int W3_TW = 28, W3_HW = 30, W3_HP = 10 * 30, W3_PX = 8 * 28;
 constexpr int W3_XW = (W3_HP * 8 + 63) / 64;          // x-halo DMA wave-instructions (38)
 constexpr int W3_XBUF = W3_XW * 512;                  // bf16 elements per x-halo buffer
 constexpr int W3_DBUF = W3_PX * 64;                   // bf16 elements per gradient-tile buffer
-#ifndef W3_CDMA
-#define W3_CDMA 1       // 1: the consumer waves issue the x-halo DMAs (their vector-memory port is otherwise idle); 0: the producers
+#ifndef W3_DEFAULT
+#define W3_DEFAULT 1    // generation of the fused kernel: 0 second (conv_wgrad.hip), 1 third (this file); 2, 3: experiment builds only
 #endif
 #ifndef W3_RING
-#define W3_RING 4
+#define W3_RING 6
 #endif
 constexpr size_t W3_LDS = (size_t)2 * (W3_XBUF + W3_DBUF) * 2;
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
         // the counted wait leaves the stores in flight across the barrier.  (The builtin, not inline assembly: the compiler's own
         // wait-count pass then knows that the prefetched registers are valid and adds no wait of its own in front of their use.)
         auto publish = [&]() {
-            if (W3_CDMA || (HYB_ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0070 | 0xc00f);      // lgkmcnt(0): only the image's LDS writes must be done
+            if (HYB_ABL & 16) __builtin_amdgcn_s_waitcnt(0x0070 | 0xc00f);                    // (ablation: lgkmcnt(0) only)
             else if (HYB_ABL & 8) __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
             else __builtin_amdgcn_s_waitcnt(0x0078);                                           // vmcnt(8) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
         {
             const W3Tile t0 = tl(0);
             fuse_load(t0, true, ua);
-            if (!W3_CDMA) x_dma(t0, xbuf);
+            x_dma(t0, xbuf);
             fuse_load(tl(1), tcount > 1, ub);
             W2_KEEP_EARLY;
             fuse_compute(t0, ua, dbuf);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
             {
                 const W3Tile t1 = tl(i + 1);
                 fuse_load(tl(i + 2), i + 2 < tcount && !(HYB_ABL & 32), ua);
-                if (!W3_CDMA && !(HYB_ABL & 16)) x_dma(t1, xbuf + W3_XBUF);
+                if (!(HYB_ABL & 16)) x_dma(t1, xbuf + W3_XBUF);
                 W2_KEEP_EARLY;
                 fuse_compute(t1, ub, dbuf + W3_DBUF);
                 publish();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
             {
                 const W3Tile t2 = tl(i + 2);
                 fuse_load(tl(i + 3), i + 3 < tcount && !(HYB_ABL & 32), ub);
-                if (!W3_CDMA && !(HYB_ABL & 16)) x_dma(t2, xbuf);
+                if (!(HYB_ABL & 16)) x_dma(t2, xbuf);
                 W2_KEEP_EARLY;
                 fuse_compute(t2, ua, dbuf);
                 publish();
@@ -239,13 +239,8 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    if (W3_CDMA) {
-        x_dma(w3_tile(tbegin, tilesX, tilesY, H), xbuf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     __builtin_amdgcn_s_barrier();                      // barrier 1: tile 0 staged
     for (int it = 0; it < tcount; ++it) {
-        if (W3_CDMA && it + 1 < tcount && !(HYB_ABL & 16)) x_dma(w3_tile(tbegin + it + 1, tilesX, tilesY, H), xbuf + ((it + 1) & 1) * W3_XBUF);
         const bf16* xb = xbuf + (it & 1) * W3_XBUF;
         const bf16* db = dbuf + (it & 1) * W3_DBUF;
         const int rows = w3_tile(tbegin + it, tilesX, tilesY, H).rows;
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
             __builtin_amdgcn_sched_barrier(0);      // keep the reads where they are: hoisted further ahead they cost accumulator spills
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // (this wave's DMAs of the next x halo have landed)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // the other pair of images is complete, this pair may be overwritten
     }
 
@@ -307,9 +302,9 @@ inline int w3_supported(int H, int W, int Cip, int Cop) {
 #ifdef HYB_NO_V3
     static const int v3 = 0;
 #else
-    static const int v3 = getenv("HYB_WGRAD_V3") ? atoi(getenv("HYB_WGRAD_V3")) : 1;
+    static const int v3 = getenv("HYB_WGRAD_V3") ? atoi(getenv("HYB_WGRAD_V3")) : W3_DEFAULT;
 #endif
-    return v3 && Cip % 64 == 0 && Cop % 64 == 0 && W % W3_TW == 0 && H % 4 == 0 && H >= 8;
+    return (Cip % 64 == 0 && Cop % 64 == 0 && W % W3_TW == 0 && H % 4 == 0 && H >= 8) ? v3 : 0;
 }
 
 inline int w3_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, float* slab, int N, int H, int W, int Cip, int Cop, int tX, int tY,
