@@ -49,7 +49,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (defaults of the flags below)")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=None)

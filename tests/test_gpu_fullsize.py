@@ -9,7 +9,7 @@
        stack within 1e-3 of the fp32 oracle; the conv-stack gradients (3-6 M summed products per element behind max-pool / ReLU
        routing, where the fp32 oracle is itself 1e-3..9e-3 away from its own fp64 run) within 5e-3 of the FP64 oracle;
      * bf16 mode is REPORTED against the fp32 oracle and against the bf16-rounded oracle (oracle/hybrid_ref_bf16.py) and gated
-       at about twice the measured end-to-end distances (logits 1.5e-2, gradients 1e-1 relative L2).  End to end the rounded oracle
+       at 1.3 x the distances measured for this build (BF16_MEASURED below: logits 6.5e-3 .. 9.8e-3, gradients 5.5e-2 .. 6.3e-2 relative L2).  End to end the rounded oracle
        cannot be tight -- rounding amplifies any summation-order difference to bf16 noise within a few stages (its docstring) --
        so the TIGHT bf16 gates (2e-3 forward, 2e-2 gradients) live in the per-stage tests of tests/test_gpu_parity.py.
 2. SIZE-INDEPENDENT PROPERTIES (kept from round 1): bit-identical repeat runs, clip independence (what makes batch-of-clips
@@ -206,6 +206,37 @@ def test_fullsize_fp32_mode_matches_the_oracle(name, cfg):
 
 
 @pytest.mark.parametrize("name,cfg", ORACLE_CFGS, ids=[n for n, _ in ORACLE_CFGS])
+def test_fullsize_bf16x3_mode_meets_the_north_star_tolerance(name, cfg):
+    """compute_dtype="bf16x3" -- fp32 storage, every contraction product from three bf16 MFMAs on two-term splits (hyb_common.h) -- is
+    the fast mode that still meets north_star's 1e-3: logits and loss within 1e-3 of the fp32 oracle (measured ~1e-5), gradients
+    outside the conv stack within 1.7e-2 of the fp32 oracle (max-abs over the tensor's max; measured 2.8e-3 / 8.1e-3 / 1.27e-2 at configs
+    2 / 4 / 5, the worst being the tiny key-projection gradients, where the softmax backward's dP - delta cancels; the FFN / projection
+    weight gradients also sit behind ReLU decisions, and a pre-activation within 1e-5 of zero switches a whole hidden unit's
+    contribution), conv-stack gradients within 1.2e-2 of the fp64 oracle (measured 8.1e-3 .. 8.8e-3) (ReLU and arg-max routing; the exact-fp32 mode is gated at 5e-3 there and the fp32 CPU oracle itself is up to
+    9e-3 from fp64)."""
+    orc = _oracle(name, cfg)
+    f32, f64 = orc["fp32"], orc["fp64"]
+    logits, loss, grads, running = _hip_step(cfg, "bf16x3", orc)
+    e_log = _maxrel(logits, f32["logits"])
+    G = max(g.abs().max().item() for g in f64["grads"].values())
+    e_hip = {n: _maxrel(grads[n], f64["grads"][n], floor=1e-4 * G) for n in grads}
+    e_two = {n: _maxrel(grads[n], f32["grads"][n], floor=1e-4 * G) for n in grads}
+    conv = [n for n in grads if n.startswith("encoder") and not n.startswith("encoder.")]
+    rest = [n for n in grads if n not in conv]
+    wc, wr = max(conv, key=lambda n: e_hip[n]), max(rest, key=lambda n: e_two[n])
+    print(f"\n[{name} bf16x3] logits max-rel {e_log:.2e} vs fp32 oracle; loss {loss:.6f} vs {f32['loss']:.6f}; worst conv-stack gradient vs fp64 "
+          f"{e_hip[wc]:.2e} ({wc}); worst other gradient vs fp32 oracle {e_two[wr]:.2e} ({wr})")
+    assert e_log <= 1e-3
+    assert abs(loss - f32["loss"]) <= 1e-3 * max(1.0, abs(f32["loss"]))
+    for n in conv:
+        assert e_hip[n] <= 1.2e-2, (n, e_hip[n])          # measured 8.1e-3 / 8.6e-3 / 8.8e-3 (configs 2 / 4 / 5)
+    for n in rest:
+        assert e_two[n] <= 1.7e-2, (n, e_two[n])          # measured 2.8e-3 / 8.1e-3 / 1.27e-2
+    for k, v in f32["running"].items():
+        assert _maxrel(running[k], v) <= 1e-4, k
+
+
+@pytest.mark.parametrize("name,cfg", ORACLE_CFGS, ids=[n for n, _ in ORACLE_CFGS])
 def test_fullsize_bf16_mode_against_both_oracles(name, cfg):
     """bf16 (the benchmarked mode): reported against the fp32 oracle and the bf16-rounded oracle; loose end-to-end gates (module docstring)."""
     orc = _oracle(name, cfg)
@@ -222,8 +253,15 @@ def test_fullsize_bf16_mode_against_both_oracles(name, cfg):
           f"{_maxrel(r16['logits'], f32['logits']):.2e} on the logits")
     print("   per-gradient L2-rel vs rounded oracle: " + ", ".join(f"{n.replace('encoder', 'e').replace('.weight', '.w').replace('.bias', '.b')} {v:.1e}"
                                                                for n, v in rep16.items() if v > 5e-3))
-    assert e32 <= 3e-2                                            # sanity bound only: bf16 cannot meet 1e-3 (reported above)
-    assert e16 <= 1.5e-2, e16
+    # gates = 1.3 x what this build measures at this config (the runs are bit-reproducible): (logits vs fp32 oracle, logits vs rounded
+    # oracle, worst gradient L2-rel vs rounded oracle).  bf16 cannot meet north_star's 1e-3 -- compute_dtype="bf16x3" does (test above).
+    m32, m16, mg = BF16_MEASURED[name]
+    assert e32 <= 1.3 * m32, e32
+    assert e16 <= 1.3 * m16, e16
     assert abs(loss - r16["loss"]) <= 5e-3 * max(1.0, abs(r16["loss"]))
     for n, e in rep16.items():
-        assert e <= 1e-1, (n, e)
+        assert e <= 1.3 * mg, (n, e)
+
+
+# round 3, measured on MI355X (gpurun_out/r3_fullsize2.log; profiles/r03_bf16_error_table.txt)
+BF16_MEASURED = {"config2": (9.75e-3, 8.32e-3, 5.45e-2), "config4_B4_T64_d768": (8.73e-3, 5.47e-3, 5.93e-2), "config5_448": (6.53e-3, 4.48e-3, 6.25e-2)}

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import transformer_cnn_hybrid_network_for_video_processing_amd as P
-from transformer_cnn_hybrid_network_for_video_processing_amd import _lib
+from transformer_cnn_hybrid_network_for_video_processing_amd import _lib, ops
 from oracle import hybrid_ref as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,10 +70,22 @@ def test_argument_checks_fail_without_a_device(built):
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-    fresh = _lib._Lib()
-    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    fresh = _lib._Lib(str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
         fresh.call("hyb_abi_version")
+
+
+def test_split_bf16_build_serves_the_same_abi(built):
+    """compute_dtype="bf16x3" = the second build of the library (-DHYB_F32_X3): every declared symbol is there, and a call whose first
+    argument is the host-side dtype code HYB_F32X3 is routed to it with HYB_F32 in its place."""
+    assert ops.dtype_code("bf16x3") == _lib.HYB_F32X3 and ops.torch_dtype(_lib.HYB_F32X3) is torch.float32
+    for name in built.protos:
+        built.x3.raw(name)
+    assert built.x3.query("hyb_abi_version") == built.query("hyb_abi_version")
+    assert "hyb_convstage_fwd" in _lib.DTYPE_FIRST and "hyb_abi_version" not in _lib.DTYPE_FIRST
+    assert built.query("hyb_encoder_saved_bytes", _lib.HYB_F32X3, 8, 16, 512, 2048, 2, 8) == built.query("hyb_encoder_saved_bytes", _lib.HYB_F32, 8, 16, 512, 2048, 2, 8)
+    with pytest.raises(RuntimeError, match="argument check"):                  # reaches the x3 library's own argument check
+        built.call("hyb_gap_fwd", _lib.HYB_F32X3, None, None, 1, 1, 32, None)
 
 
 def test_module_contract_matches_reference_and_oracle():

@@ -9,8 +9,11 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 HEADER = os.path.join(ROOT, "include", "hybrid_hip.h")
 LIB_PATH = os.path.join(PKG, "libhybrid_hip.so")
+LIB_X3_PATH = os.path.join(PKG, "libhybrid_hip_x3.so")
 
-HYB_F32, HYB_BF16 = 0, 1
+# dtype codes of the C ABI (include/hybrid_hip.h) -- and HYB_F32X3, which exists on the host side only: the SAME ABI served by the second
+# build of the library (libhybrid_hip_x3.so, -DHYB_F32_X3), where HYB_F32 means "fp32 storage, products from split-bf16 MFMAs"
+HYB_F32, HYB_BF16, HYB_F32X3 = 0, 1, 2
 
 _CTYPES = {
     "int": ctypes.c_int,
@@ -22,12 +25,16 @@ _CTYPES = {
 }
 
 
+DTYPE_FIRST = set()          # entry points whose first parameter is `int dtype`
+
+
 def parse_header(path=HEADER):
     """-> {name: (restype_str, [argtype_str, ...])} for every function declared in the header."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
+    DTYPE_FIRST.clear()
     for m in re.finditer(r"\b(int|size_t|long long)\s+(hyb_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
@@ -41,23 +48,26 @@ def parse_header(path=HEADER):
                     a = re.sub(r"\s+\w+$", "", a).strip()      # drop the parameter name
                     argtypes.append(a)
         protos[name] = (ret, argtypes)
+        if re.match(r"\s*int\s+dtype\b", args):
+            DTYPE_FIRST.add(name)
     return protos
 
 
 class _Lib:
-    def __init__(self):
+    def __init__(self, path=LIB_PATH):
         self._dll = None
+        self._path = path
         self.protos = parse_header()
 
     def _load(self):
         if self._dll is not None:
             return self._dll
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(self._path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+                f"{self._path} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `python -m transformer_cnn_hybrid_network_for_video_processing_amd.build`). "
                 "There is no CPU/eager fallback for this path.")
-        dll = ctypes.CDLL(LIB_PATH)
+        dll = ctypes.CDLL(self._path)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype = _CTYPES[ret]
@@ -80,7 +90,26 @@ class _Lib:
         return getattr(self._load(), name)(*args)
 
 
-lib = _Lib()
+class _Mux(_Lib):
+    """The library as the host code sees it: calls whose first argument is the dtype code HYB_F32X3 go to the split-bf16 build with
+    HYB_F32 in its place; everything else to the main build."""
+
+    def __init__(self):
+        super().__init__(LIB_PATH)
+        self.x3 = _Lib(LIB_X3_PATH)
+
+    def call(self, name, *args):
+        if args and args[0] == HYB_F32X3 and name in DTYPE_FIRST and not isinstance(args[0], bool):
+            return self.x3.call(name, HYB_F32, *args[1:])
+        return super().call(name, *args)
+
+    def query(self, name, *args):
+        if args and args[0] == HYB_F32X3 and name in DTYPE_FIRST and not isinstance(args[0], bool):
+            return self.x3.query(name, HYB_F32, *args[1:])
+        return super().query(name, *args)
+
+
+lib = _Mux()
 
 
 def ptr_array(ptrs):

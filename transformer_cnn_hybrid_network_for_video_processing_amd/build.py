@@ -9,6 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhybrid_hip.so")
+LIB_X3 = os.path.join(PKG, "libhybrid_hip_x3.so")     # the same sources with -DHYB_F32_X3: fp32 storage, split-bf16 products (hyb_common.h)
 SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "side.hip", "fct.hip", "fct_bwd.hip", "bn2d.hip", "optim.hip"]
 
 
@@ -24,41 +25,47 @@ def _hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_X3):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_X3))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "hybrid_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, jobs=4):
-    """Compile every HIP source for gfx950 and link the shared object next to this file."""
+def build(force=False, verbose=False, jobs=8):
+    """Compile every HIP source for gfx950 and link the two shared objects next to this file: libhybrid_hip.so and, from the same
+    sources with -DHYB_F32_X3, libhybrid_hip_x3.so (compute_dtype="bf16x3")."""
     if not force and not needs_build():
         return LIB
-    objdir = os.path.join(PKG, "build")
-    os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
              "-Wno-unused-result"] + os.environ.get("HYB_EXTRA_FLAGS", "").split()
-    procs, objs = [], []
-    for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        objs.append(obj)
-        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        if len(procs) >= jobs:
-            _drain(procs)
-    _drain(procs)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    variants = [("build", [], LIB), ("build_x3", ["-DHYB_F32_X3"], LIB_X3)]
+    procs, links = [], []
+    for objdir_name, extra, out in variants:
+        objdir = os.path.join(PKG, objdir_name)
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for src in SOURCES:
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(obj)
+            cmd = [_hipcc()] + flags + extra + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            if len(procs) >= jobs:
+                _drain(procs, 1)
+        links.append((out, objs))
+    _drain(procs, 0)
+    for out, objs in links:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode())
     return LIB
 
 
-def _drain(procs):
-    while procs:
+def _drain(procs, leave):
+    while len(procs) > leave:
         src, p = procs.pop(0)
         out = p.communicate()[0].decode()
         if p.returncode != 0:

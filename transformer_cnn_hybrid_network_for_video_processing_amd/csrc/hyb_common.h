@@ -67,11 +67,31 @@ template <> struct Frag<float> { float v[8]; };
 __device__ __forceinline__ f32x4 mma32(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
 }
+#ifdef HYB_F32_X3
+// libhybrid_hip_x3.so ("bf16x3" mode of the host side): fp32 STORAGE everywhere, but every product of a contraction is formed on the
+// bf16 matrix cores from the two-term splits x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits):
+//   a*b ~ hi_a*hi_b + hi_a*lo_b + lo_a*hi_b      (the dropped lo*lo term is 2^-16 relative), fp32 accumulation,
+// three v_mfma_f32_16x16x32_bf16 (48 cycles) instead of eight v_mfma_f32_16x16x4_f32 (256 cycles) per 32-deep step.  The splits of a
+// fragment are pure functions of it: the compiler forms them once per fragment, not once per product.
+__device__ __forceinline__ void hyb_split_bf16(const Frag<float>& f, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { hi[j] = (bf16)f.v[j]; lo[j] = (bf16)(f.v[j] - (float)hi[j]); }
+}
+__device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+    bf16x8 ah, al, bh, bl;
+    hyb_split_bf16(a, ah, al);
+    hyb_split_bf16(b, bh, bl);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);      // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+#else
 __device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
     return c;
 }
+#endif
 
 // load a fragment from 8 consecutive T (16-byte aligned for bf16, 16-byte aligned for fp32)
 __device__ __forceinline__ void frag_load(Frag<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const bf16x8*>(p); }

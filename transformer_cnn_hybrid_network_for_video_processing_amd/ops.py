@@ -29,9 +29,9 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from ._lib import HYB_BF16, HYB_F32, lib, ptr_array
+from ._lib import HYB_BF16, HYB_F32, HYB_F32X3, lib, ptr_array
 
-_TORCH_DTYPE = {HYB_F32: torch.float32, HYB_BF16: torch.bfloat16}
+_TORCH_DTYPE = {HYB_F32: torch.float32, HYB_BF16: torch.bfloat16, HYB_F32X3: torch.float32}
 _LIB = torch.library.Library("hybrid", "DEF")
 _below_autograd = torch._C._AutoDispatchBelowAutograd
 
@@ -49,13 +49,15 @@ _SEED_MASK = 0x7FFFFFFFFFFFFFFF          # operator schemas carry ints as int64
 
 
 def dtype_code(name):
-    if isinstance(name, int) and not isinstance(name, bool) and name in (HYB_F32, HYB_BF16):
+    if isinstance(name, int) and not isinstance(name, bool) and name in (HYB_F32, HYB_BF16, HYB_F32X3):
         return name
+    if isinstance(name, str) and name == "bf16x3":       # fp32 storage, every contraction product from three bf16 MFMAs (hyb_common.h)
+        return HYB_F32X3
     if isinstance(name, str) and name in ("fp32", "float32") or name is torch.float32:
         return HYB_F32
     if isinstance(name, str) and name in ("bf16", "bfloat16") or name is torch.bfloat16:
         return HYB_BF16
-    raise ValueError(f"compute dtype must be 'bf16' or 'fp32', got {name!r}")
+    raise ValueError(f"compute dtype must be 'bf16', 'bf16x3' or 'fp32', got {name!r}")
 
 
 def torch_dtype(code):
