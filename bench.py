@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fwd-bwd-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive leg (host uint8 clips fed through clips.ClipPipeline)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short extra legs printed beside the headline (config 4 / 5, fp32 and bf16x3 "
+                                                                 "modes, FCT, Encoder_32K, config-1 CPU baseline, the in-run bf16 logits check)")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python each step instead of replaying the captured hipGraphs "
                                                          "(graph.GraphedTrainStep); same kernels and arithmetic, more host time")
     args = ap.parse_args(argv)
@@ -264,7 +266,7 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, budget_s=25.0):
     """The oracle (a port: stock torch fp32 on the host cores) on a bounded sample: 1 clip of the same shape."""
     _import_torch()
     from oracle import hybrid_ref as R
@@ -283,7 +285,7 @@ def cpu_baseline(args):
         opt.step()
     step()
     times = []
-    t_budget = time.time() + 25.0
+    t_budget = time.time() + budget_s
     while len(times) < 5 and time.time() < t_budget:
         t0 = time.time()
         step()
@@ -293,6 +295,257 @@ def cpu_baseline(args):
     return dict(value=1.0 / med, unit="clips/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle/hybrid_ref.py fp32, 1 clip [1,{args.frames},3,{args.size},{args.size}] x {len(times)} full steps "
                        f"(median {med * 1e3:.0f} ms) after 1 warm-up")
+
+
+class EntryPointTimer:
+    """HIP events (torch's current stream = the stream the library launches on) around every C-ABI call while active:
+    per (entry point, shape key) call count and total GPU milliseconds -- live, inside real passes, no synchronisation per call."""
+
+    KEYS = {"hyb_fct_mha_bwd": slice(14, 18), "hyb_fct_mha_fwd": slice(9, 13), "hyb_conv2d_bwd": slice(7, 17), "hyb_conv2d_fwd": slice(5, 15),
+            "hyb_fct_conv_bwd": slice(8, 16), "hyb_fct_conv_fwd": slice(5, 12)}
+
+    def __enter__(self):
+        _import_torch()
+        from transformer_cnn_hybrid_network_for_video_processing_amd import _lib
+        self._lib, self._orig, self.rec = _lib, _lib._Lib.call, []
+        timer = self
+
+        def call(lib_self, name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer._orig(lib_self, name, *args)
+            e1.record()
+            key = tuple(a for a in args[self.KEYS[name]]) if name in self.KEYS else ()
+            timer.rec.append((name, key, args[4] is not None if name == "hyb_conv2d_bwd" else True, e0, e1))
+            return r
+        _lib._Lib.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self._lib._Lib.call = self._orig
+        torch.cuda.synchronize()
+        tot = {}
+        for name, key, flag, e0, e1 in self.rec:
+            t = tot.setdefault((name, key, flag), [0, 0.0])
+            t[0] += 1
+            t[1] += e0.elapsed_time(e1)
+        self.totals = tot
+        return False
+
+
+def entry_point_roofline(totals, passes):
+    """The heaviest (entry point, shape) of a pass against the fp32 matrix peak (these rows compute in fp32)."""
+    by_name = {}
+    for (n_, _, _), (_, t_) in totals.items():
+        by_name[n_] = by_name.get(n_, 0.0) + t_
+    top = max(by_name, key=by_name.get)                                     # the entry point with the largest share of the pass ...
+    (name, key, flag), (calls, ms) = max(((k, v) for k, v in totals.items() if k[0] == top), key=lambda kv: kv[1][1])      # ... and its heaviest shape
+    ms_call = ms / calls
+    flops, what = None, name
+    if name in ("hyb_fct_mha_bwd", "hyb_fct_mha_fwd"):
+        N, L, C, heads = key
+        flops = (10.0 if name.endswith("bwd") else 4.0) * N * L * L * C + (16.0 if name.endswith("bwd") else 8.0) * N * L * C * C
+        what = f"{name} N={N} L={L} C={C} heads={heads}: one call = the attention kernels over {L}-token sequences + the in/out projections"
+    elif name in ("hyb_conv2d_bwd", "hyb_conv2d_fwd"):
+        N, H, W, Ci, Co, k, stride, pad, dil = key[:9]
+        Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        flops = 2.0 * N * Ho * Wo * Co * Ci * k * k * ((2 if flag else 1) if name.endswith("bwd") else 1)
+        what = f"{name} N={N} {H}x{W} Ci={Ci} Co={Co} k={k} stride={stride}" + (" (dx + dw)" if name.endswith("bwd") and flag else "")
+    total = sum(v[1] for v in totals.values())
+    r = {"entry_point": what, "calls_per_pass": calls // passes, "ms_per_call": ms_call, "share_of_pass": ms / total,
+         "entry_point_share_of_pass": by_name[top] / total, "bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS,
+         "unit": "TFLOP/s", "traffic": None,
+         "how": "HIP events recorded on the launch stream around every C-ABI call inside real training passes; the heaviest (entry point, shape)"}
+    if flops is not None:
+        r.update(achieved=flops / (ms_call * 1e-3) / 1e12, frac=flops / (ms_call * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, flops_per_call=flops)
+    return r
+
+
+def model_leg(cfgno, dtype, dev, steps, warmup, want_roofline):
+    """A short run of one more configuration / precision mode: the same full step as the headline (graph replay when capture works)."""
+    _import_torch()
+    import transformer_cnn_hybrid_network_for_video_processing_amd as P
+    from transformer_cnn_hybrid_network_for_video_processing_amd import ops
+    c = CONFIGS[cfgno]
+    ns = argparse.Namespace(batch=c["batch"], frames=c["frames"], size=c["size"], d_model=c["d_model"], heads=c["num_heads"], hidden=c["hidden_dim"], dtype=dtype,
+                            config=cfgno)
+    torch.manual_seed(0)
+    model = P.TransformerCNNHybrid(cnn_channels=CFG["cnn_channels"], d_model=ns.d_model, num_heads=ns.heads, num_layers=CFG["num_layers"],
+                                   hidden_dim=ns.hidden, num_classes=CFG["num_classes"], dropout=0.0, compute_dtype=dtype).to(dev).train()
+    crit, opt = P.HybridCrossEntropyLoss(), None
+    opt = P.HybridAdamW(model.parameters(), lr=1e-3)
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    x = torch.rand(ns.batch, ns.frames, 3, ns.size, ns.size, generator=g).to(dev)
+    y = torch.randint(0, CFG["num_classes"], (ns.batch,), generator=g).to(dev)
+    trainer, fallback = None, None
+    try:
+        trainer = P.GraphedTrainStep(model, crit, opt, x, y)
+        step, fwd_bwd = trainer.step, trainer.eager_fwd_bwd
+    except Exception as e:                                                  # noqa: BLE001 (reported)
+        fallback = f"{type(e).__name__}: {e}"[:200]
+        ops.set_step_counter(None); opt.set_step_counter(None)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(x), y)
+            loss.backward()
+            opt.step()
+            return loss
+        fwd_bwd = step
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"value": ns.batch * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype,
+           "workload": f"config {cfgno}: clips [{ns.batch},{ns.frames},3,{ns.size},{ns.size}], d={ns.d_model} h={ns.heads} hid={ns.hidden}; full step",
+           "graph_fallback": fallback is not None, "final_loss": float(loss.item())}
+    if fallback:
+        res["graph_fallback_reason"] = fallback
+    if want_roofline and dtype == "bf16":
+        rows = instep_kernel_table(ns, fwd_bwd, nsteps=4)
+        dom = dominant_kernel(rows)
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms": dom["ms"], "flops_per_launch": dom["flops"],
+                           "how": "HIP events recorded by the library around this kernel inside 4 real steps (hyb_profile_set)"}
+    if trainer is not None:
+        trainer.close()
+    ops.set_step_counter(None)
+    del model, opt, x, y, trainer
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def fct_leg(dev, reps=5, frames=16, size=224):
+    """FCT: the reference's training step (FCT.py:328-338: forward, DiceLoss, backward) on frame-folded clips, fp32."""
+    _import_torch()
+    import transformer_cnn_hybrid_network_for_video_processing_amd as P
+    torch.manual_seed(0)
+    m = P.FCT().to(dev).train()
+    crit = P.DiceLoss()
+    x = torch.rand(frames, 3, size, size, device=dev)
+    yt = (torch.rand(frames, 1, size, size, device=dev) > 0.5).float()
+
+    def train_pass():
+        for p_ in m.parameters():
+            p_.grad = None
+        crit(m(x), yt).backward()
+    train_pass(); train_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        train_pass()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    with EntryPointTimer() as ept:
+        train_pass(); train_pass()
+    res = {"value": frames / ms * 1e3, "unit": "frames/s", "ms_per_pass": ms, "dtype": "f32",
+           "workload": f"FCT training pass (forward + DiceLoss + backward, train mode), frames [{frames},3,{size},{size}]",
+           "roofline": entry_point_roofline(ept.totals, 2)}
+    from oracle import fct_ref as F
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ref = F.FCT().train()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    n = 2
+    xc, yc = x[:n].cpu(), yt[:n].cpu()
+    F.DiceLoss()(ref(xc), yc).backward()
+    t0 = time.time()
+    F.DiceLoss()(ref(xc), yc).backward()
+    dt = time.time() - t0
+    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"oracle/fct_ref.py, one training pass on {n} frames [{n},3,{size},{size}] after 1 warm-up ({dt * 1e3:.0f} ms)"}
+    del m, x, yt
+    gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+def enc32k_leg(dev, reps=5, frames=16):
+    """Encoder_32K: training pass (train-mode forward with Dropout2d + backward) on frame-folded 256 x 256 frames, fp32."""
+    _import_torch()
+    import transformer_cnn_hybrid_network_for_video_processing_amd as P
+    torch.manual_seed(0)
+    m = P.Encoder_32K().to(dev).train()
+    x = torch.rand(frames, 3, 256, 256, device=dev)
+
+    def train_pass():
+        for p_ in m.parameters():
+            p_.grad = None
+        m(x).square().mean().backward()
+    train_pass(); train_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        train_pass()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    with EntryPointTimer() as ept:
+        train_pass(); train_pass()
+    res = {"value": frames / ms * 1e3, "unit": "frames/s", "ms_per_pass": ms, "dtype": "f32",
+           "workload": f"Encoder_32K training pass (forward + backward, train mode), frames [{frames},3,256,256] -> tokens [{frames},8,4096]; 72 GFLOP per frame",
+           "tflops": 72.0 * frames / ms, "roofline": entry_point_roofline(ept.totals, 2)}
+    from oracle import encoder32k_ref as E
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    n = 2
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    xc = x[:n].cpu()
+    E.forward(p, xc, True).square().mean().backward()
+    t0 = time.time()
+    E.forward(p, xc, True).square().mean().backward()
+    dt = time.time() - t0
+    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"oracle/encoder32k_ref.py, one training pass on {n} frames after 1 warm-up ({dt * 1e3:.0f} ms)"}
+    del m, x
+    gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+def config1_cpu_baseline():
+    """BASELINE.json config 1: the reference's own CPU-runnable case, one clip [1,8,3,112,112] through the oracle (plumbing, no GPU)."""
+    ns = argparse.Namespace(frames=8, size=112, d_model=512, heads=8, hidden=2048)
+    r = cpu_baseline(ns, budget_s=10.0)
+    r["workload"] = "config 1: clips [1,8,3,112,112], d=512 h=8 hid=2048"
+    return r
+
+
+def bf16_logits_check(dev):
+    """The bf16 mode's forward error of THIS build in THIS run: 2 clips [2,16,3,224,224] (train-mode BatchNorm, dropout off) against the
+    fp32 CPU oracle on the same weights; max|dlogits| / max|logits| (the statistic of tests/test_gpu_fullsize.py)."""
+    _import_torch()
+    import transformer_cnn_hybrid_network_for_video_processing_amd as P
+    from oracle import hybrid_ref as R
+    torch.set_num_threads(host_cores())
+    torch.manual_seed(0)
+    ref = R.TransformerCNNHybridRef(cnn_channels=CFG["cnn_channels"], d_model=512, num_heads=8, num_layers=2, hidden_dim=2048, num_classes=8)
+    for a in ref.encoder.attention_layers:
+        a.dropoutLayer.p = 0.0
+    ref.train()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    x, _ = R.synthetic_batch(2, 16, 224, 224, seed=0)
+    with torch.no_grad():
+        lr = ref(x)
+    out = {}
+    for mode in ("bf16", "bf16x3", "fp32"):
+        m = P.TransformerCNNHybrid(compute_dtype=mode)
+        m.load_state_dict(sd)
+        for a in m.encoder.attention_layers:
+            a.dropoutLayer.p = 0.0
+        m = m.to(dev).train()
+        with torch.no_grad():
+            lh = m(x.to(dev))
+        out[mode] = float(((lh.cpu() - lr).abs().max() / lr.abs().max()).item())
+        del m
+    out["what"] = "max|dlogits| / max|logits| vs oracle/hybrid_ref.py (fp32, host) on 2 clips [2,16,3,224,224], same weights, measured in this run"
+    return out
 
 
 def main():
@@ -484,8 +737,10 @@ def main():
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",
-                       "logits_parity": "fp32 mode: <=1e-3 rel vs the CPU oracle (north_star gate); bf16 mode: ~5e-3 (reported, tests/test_gpu_fullsize.py)"},
+                       "logits_parity": "north_star's 1e-3 rel vs the CPU oracle is met by compute_dtype fp32 (exact fp32 MFMA) and bf16x3 (split-bf16 "
+                                        "products); bf16 mode is at bf16 rounding level -- all three measured in this run: key logits_check"},
             "final_loss": final_loss,
+            "graph_fallback": bool(graph_fallback),
         }
         if fb is not None:
             out["fwd_bwd_only"] = fb
@@ -513,6 +768,26 @@ def main():
                                     "GBps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+        # the extra legs belong to the plain command (what the driver runs); the trimmed forms the profiling scripts use skip them
+        if not (args.no_extra_legs or args.no_roofline or args.no_cpu_baseline or args.eager) and world == 1 and is_cfg and args.config == 2 and args.dtype == "bf16":
+            # free the headline's model and graphs first: config 4 wants the memory
+            if graphed:
+                trainer.close()
+            ops.set_step_counter(None)
+            del model, opt, x, y
+            gc.collect()
+            torch.cuda.empty_cache()
+            legs = (("config4", lambda: model_leg(4, "bf16", dev, 10, 3, True)), ("config5", lambda: model_leg(5, "bf16", dev, 10, 3, True)),
+                    ("fp32", lambda: model_leg(2, "fp32", dev, 10, 3, False)), ("bf16x3", lambda: model_leg(2, "bf16x3", dev, 10, 3, False)),
+                    ("fct", lambda: fct_leg(dev)), ("enc32k", lambda: enc32k_leg(dev)), ("logits_check", lambda: bf16_logits_check(dev)),
+                    ("cpu_baseline_config1", config1_cpu_baseline))
+            for key, fn in legs:
+                if key == "cpu_baseline_config1" and args.no_cpu_baseline:
+                    continue
+                try:
+                    out[key] = fn()
+                except Exception as e:                                      # noqa: BLE001 (a failed extra leg must not lose the headline)
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
