@@ -73,6 +73,19 @@ def test_bench_plain_form_launches_its_own_ranks():
     assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
 
 
+def test_graph_and_eager_dp_steps_end_bit_equal():
+    """Multi-GPU readiness that one GPU can prove: two gloo ranks sharing cuda:0 run K steps through GraphedTrainStep and
+    K steps through the eager GradAllReducer from the same weights and shards; the parameters and BatchNorm buffers must be bit-equal
+    between the two implementations on every rank, and equal across ranks (tests/dp_equiv_worker.py).  No N > 1 RCCL run exists yet."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_equiv_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("DPEQ")]
+    assert r.returncode == 0, "\n".join(lines) + "\n" + r.stderr.decode()[-2000:]
+    assert len(lines) == 2 and all("mismatching tensors []" in l and "all ranks equal True" in l for l in lines), lines
+
+
 _RCCL_SNIPPET = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)

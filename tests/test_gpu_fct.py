@@ -209,12 +209,12 @@ def test_resample_concat_add_dice():
 
 
 @pytest.mark.parametrize("name,ctor,extra", [
-    ("g3_fct_block_first.npz", lambda: fct().Block_encoder_bottleneck("first", 3, 8, 2), ()),
-    ("g3b_fct_block_second.npz", lambda: fct().Block_encoder_bottleneck("second", 8, 16, 2), ("scale_img",)),
+    ("g3_fct_block_first.npz", lambda: fct().Block_encoder_bottleneck("first", 3, 8, 2, 0), ()),          # the reference's own 5-argument call (make_golden.py)
+    ("g3b_fct_block_second.npz", lambda: fct().Block_encoder_bottleneck("second", 8, 16, 2, 0), ("scale_img",)),
     ("g4_fct_attention.npz", lambda: fct().Attention(8, 2), ()),
     ("g4b_fct_transformer.npz", lambda: fct().Transformer(8, 8, 2), ()),
     ("g5_fct_wide_focus.npz", lambda: fct().Wide_Focus(8, 8), ()),
-    ("g6_fct_block_decoder.npz", lambda: fct().Block_decoder(16, 8, 2), ("skip",)),
+    ("g6_fct_block_decoder.npz", lambda: fct().Block_decoder(16, 8, 2, 0), ("skip",)),
     ("g6b_fct_ds_out.npz", lambda: fct().DS_out(8, 1), ()),
 ])
 def test_reference_block_goldens_forward_and_gradients(name, ctor, extra):
@@ -348,3 +348,16 @@ def test_contract_and_loud_failures():
         m.eval()(torch.rand(3, 64, 64, device="cuda"))
     with pytest.raises(AssertionError):
         P().DiceLoss()(torch.rand(1, 1, 8, 8, device="cuda"), torch.rand(1, 1, 8, 4, device="cuda"))     # Metrics.py:15
+    # the inner classes take the reference's constructor arguments (FCT.py:25,86,137,168); the ones the reference never uses are ignored
+    # like there, a conv geometry the HIP path does not implement is refused instead of computed differently
+    pkg = fct()
+    import inspect
+    for cls in ("Attention", "Transformer", "Block_encoder_bottleneck", "Block_decoder", "Wide_Focus", "DS_out"):
+        assert list(inspect.signature(getattr(pkg, cls).__init__).parameters) == list(inspect.signature(getattr(F, cls).__init__).parameters), cls
+    pkg.Block_encoder_bottleneck("first", 3, 8, 2, 0.0); pkg.Block_decoder(16, 8, 2, 0.1)
+    pkg.Transformer(8, 8, 2, dpr=0.2, proj_drop=0.5, padding_kv="valid"); pkg.Attention(8, 2, 0.5, 3, 1, 1, "valid", "same", False)
+    with pytest.raises(TypeError):
+        pkg.Block_encoder_bottleneck("first", 3, 8, 2)                 # dpr is a required positional in the reference too
+    for kw in (dict(kernel_size=5), dict(stride_kv=2), dict(stride_q=2), dict(padding_q="valid")):
+        with pytest.raises(NotImplementedError):
+            pkg.Attention(8, 2, **kw)

@@ -25,9 +25,23 @@ def _drop(x, p, training):
     return torch.ops.hybrid.fct_dropout(x, p, ops.next_seed(), ops.step_counter()) if training and p > 0.0 else x
 
 
-class Attention(nn.Module):                                       # parameter names of FCT.py:24-39
-    def __init__(self, channels, num_heads, attention_bias=True):
+def _only_fct_geometry(**given):
+    """The reference's constructors take conv geometry arguments that FCT() itself never varies (FCT.py:223-231 passes none of them).
+    The HIP path implements that one geometry; anything else is refused loudly instead of computed differently."""
+    want = dict(kernel_size=3, stride_kv=1, stride_q=1, padding_q="same")
+    for k, v in given.items():
+        if v != want[k]:
+            raise NotImplementedError(f"{k}={v!r}: the HIP path implements the geometry FCT() uses ({k}={want[k]!r}, FCT.py:25,86)")
+
+
+class Attention(nn.Module):                                       # signature and parameter names of FCT.py:24-39
+    def __init__(self, channels, num_heads, proj_drop=0.0, kernel_size=3, stride_kv=1, stride_q=1, padding_kv="same", padding_q="same",
+                 attention_bias=True):
         super().__init__()
+        # proj_drop and padding_kv are accepted and unused, exactly as in the reference (FCT.py:30 stores proj_drop and never applies it;
+        # conv_k / conv_v are built with stride_kv in the padding position, FCT.py:33,35, so padding_kv never reaches a layer)
+        _only_fct_geometry(kernel_size=kernel_size, stride_kv=stride_kv, stride_q=stride_q, padding_q=padding_q)
+        self.stride_kv, self.stride_q, self.proj_drop = stride_kv, stride_q, proj_drop
         self.num_heads = num_heads
         self.conv_q = nn.Conv2d(channels, channels, 3, 1, 1, bias=attention_bias, groups=channels)
         self.layernorm_q = nn.LayerNorm(channels, eps=1e-5)
@@ -64,9 +78,12 @@ class Wide_Focus(nn.Module):                                      # FCT.py:107-1
 
 
 class Transformer(nn.Module):                                     # FCT.py:84-91
-    def __init__(self, in_channels, out_channels, num_heads):
+    def __init__(self, in_channels, out_channels, num_heads, dpr=None, proj_drop=0.0, attention_bias=True, padding_q="same", padding_kv="same",
+                 stride_kv=1, stride_q=1):
         super().__init__()
-        self.attention_output = Attention(in_channels, num_heads)
+        # dpr (a stochastic-depth rate) is accepted and unused, as in the reference (FCT.py:86-91 never reads it)
+        self.attention_output = Attention(channels=in_channels, num_heads=num_heads, proj_drop=proj_drop, padding_q=padding_q, padding_kv=padding_kv,
+                                          stride_kv=stride_kv, stride_q=stride_q, attention_bias=attention_bias)
         self.conv1 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
         self.layernorm = nn.LayerNorm(out_channels, eps=1e-5)
         self.wide_focus = Wide_Focus(out_channels, out_channels)
@@ -78,14 +95,14 @@ class Transformer(nn.Module):                                     # FCT.py:84-91
 
 
 class Block_encoder_bottleneck(nn.Module):                        # FCT.py:136-147
-    def __init__(self, blk, in_channels, out_channels, att_heads):
+    def __init__(self, blk, in_channels, out_channels, att_heads, dpr):        # five positionals, as FCT.py:137 (dpr only travels to Transformer)
         super().__init__()
         self.blk = blk
         self.conv1_a = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
         self.conv1_b = nn.Conv2d(3, in_channels, 3, 1, padding="same")
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
         self.conv3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
-        self.trans = Transformer(out_channels, out_channels, att_heads)
+        self.trans = Transformer(in_channels=out_channels, out_channels=out_channels, num_heads=att_heads, dpr=dpr)
 
     def forward(self, x, scale_img=None):                         # FCT.py:149-162
         if self.blk in ("first", "bottleneck"):
@@ -97,12 +114,12 @@ class Block_encoder_bottleneck(nn.Module):                        # FCT.py:136-1
 
 
 class Block_decoder(nn.Module):                                   # FCT.py:167-175
-    def __init__(self, in_channels, out_channels, att_heads):
+    def __init__(self, in_channels, out_channels, att_heads, dpr):             # FCT.py:168
         super().__init__()
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, padding="same")
         self.conv2 = nn.Conv2d(out_channels * 2, out_channels, 3, 1, padding="same")
         self.conv3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding="same")
-        self.trans = Transformer(out_channels, out_channels, att_heads)
+        self.trans = Transformer(in_channels=out_channels, out_channels=out_channels, num_heads=att_heads, dpr=dpr)
 
     def forward(self, x, skip):                                   # FCT.py:177-186
         x1 = _conv(self.conv1, torch.ops.hybrid.fct_resample(x, 2), ops.ACT_RELU)
@@ -128,15 +145,16 @@ class FCT(nn.Module):
     def __init__(self):
         super().__init__()
         f, h = (8, 16, 32, 64, 128, 64, 32, 16, 8), 2
-        self.block_1 = Block_encoder_bottleneck("first", 3, f[0], h)
-        self.block_2 = Block_encoder_bottleneck("second", f[0], f[1], h)
-        self.block_3 = Block_encoder_bottleneck("third", f[1], f[2], h)
-        self.block_4 = Block_encoder_bottleneck("fourth", f[2], f[3], h)
-        self.block_5 = Block_encoder_bottleneck("bottleneck", f[3], f[4], h)
-        self.block_6 = Block_decoder(f[4], f[5], h)
-        self.block_7 = Block_decoder(f[5], f[6], h)
-        self.block_8 = Block_decoder(f[6], f[7], h)
-        self.block_9 = Block_decoder(f[7], f[8], h)
+        dpr = [0.0] * len(f)                                                      # np.linspace(0, stochastic_depth_rate = 0.0, blocks), FCT.py:218-219
+        self.block_1 = Block_encoder_bottleneck("first", 3, f[0], h, dpr[0])
+        self.block_2 = Block_encoder_bottleneck("second", f[0], f[1], h, dpr[1])
+        self.block_3 = Block_encoder_bottleneck("third", f[1], f[2], h, dpr[2])
+        self.block_4 = Block_encoder_bottleneck("fourth", f[2], f[3], h, dpr[3])
+        self.block_5 = Block_encoder_bottleneck("bottleneck", f[3], f[4], h, dpr[4])
+        self.block_6 = Block_decoder(f[4], f[5], h, dpr[5])
+        self.block_7 = Block_decoder(f[5], f[6], h, dpr[6])
+        self.block_8 = Block_decoder(f[6], f[7], h, dpr[7])
+        self.block_9 = Block_decoder(f[7], f[8], h, dpr[8])
         self.ds = DS_out(f[8], 1)
 
     def forward(self, x):
