@@ -193,13 +193,27 @@ int hyb_linear_bwd(int dtype, const void* x, int ldx, const float* W, const void
  * out = weights v.  stats: fp32 [B*H,S,2] = (row max, row sum of exp) of the scaled, masked scores -- all the backward needs to
  * recompute the probabilities (the fp32 probability matrix of the first generation is gone); pass the SAME mask, p_drop and seed
  * to the backward call.
- * Limits: S <= 64, D/H a multiple of 8, <= 128. */
+ * Limits: S <= 64 (longer sequences: hyb_attention_long_* below; hyb_encoder_* switch by themselves), D/H a multiple of 8, <= 128. */
 int hyb_attention_fwd(int dtype, const void* q, const void* k, const void* v, const float* mask,
                       void* out, float* stats, int B, int S, int D, int H, float p_drop,
                       unsigned long long seed, void* stream);
 int hyb_attention_bwd(int dtype, const void* q, const void* k, const void* v, const float* mask, const float* stats,
                       const void* dout, void* dq, void* dk, void* dv, int B, int S, int D, int H,
                       float p_drop, unsigned long long seed, void* stream);
+/* The same attention() for sequences of ANY length (the reference has no limit on S; TransformerEncoder.pyc src L49-62): online-softmax
+ * kernels over 64-key blocks, same scale / mask / dropout semantics as above.  q, k, v: rows at stride ld_qkv elements (D for separate
+ * tensors, 3 D for a packed q|k|v row), dq, dk, dv at stride ld_d; out and dout are dense [B*S, D].  lse: fp32 [B*H, S], the
+ * log-sum-exp of each query's scaled, masked scores (forward output, backward input, with the forward's `out`).  seed_inc: NULL, or a
+ * device counter added to the seed (graph replay).  workspace: hyb_attention_long_workspace bytes.  The core computes on fp32 operands;
+ * a bf16 caller's tensors are widened into the workspace and results rounded once.  Limits: D/H a multiple of 8, <= 128; B*H <= 65535. */
+size_t hyb_attention_long_workspace(int dtype, int B, int S, int D, int H);
+int hyb_attention_long_fwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const float* mask, void* out, float* lse,
+                           int B, int S, int D, int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int hyb_attention_long_bwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const float* mask, const void* out,
+                           const float* lse, const void* dout, void* dq, void* dk, void* dv, int ld_d, int B, int S, int D, int H,
+                           float p_drop, unsigned long long seed, const unsigned long long* seed_inc, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm + residual (+ scale, + dropout): src L116-117 / L120-123 ---------------
  * y = dropout_p( (LayerNorm(x)*gamma + beta + skip) * out_scale ).  stats fp32 [2][M]. */

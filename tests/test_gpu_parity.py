@@ -211,9 +211,16 @@ def test_golden_g2_reference_two_stage_on_hip():
 @pytest.mark.parametrize("B,S,D,H,use_mask", [(2, 16, 64, 4, False), (1, 1, 16, 2, False), (3, 5, 24, 3, True), (2, 33, 128, 2, True),
                                               (8, 16, 512, 8, False), (2, 64, 768, 8, False), (2, 64, 256, 2, True),
                                               (683, 7, 24, 3, False), (300, 16, 64, 8, True),      # >= 2048 problems: four per workgroup (+ a ragged last one)
-                                              (3, 40, 96, 2, True), (2, 17, 32, 4, False)])          # 3 and 2 tiles with ragged tails
+                                              (3, 40, 96, 2, True), (2, 17, 32, 4, False),           # 3 and 2 tiles with ragged tails
+                                              # more than 64 tokens: the online-softmax kernels (hyb_attention_long_*); attention() has no length
+                                              # limit in the reference (TransformerEncoder.pyc src L49-62)
+                                              (2, 96, 64, 4, False), (3, 128, 96, 2, True), (2, 70, 32, 4, True), (1, 200, 256, 2, False)])
 def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
     ftol, gtol = TOL[mode]
+    if mode == "bf16" and S > 64:
+        # the long-sequence core computes in fp32 on the bf16 q, k, v and rounds its output once, while the rounded oracle models the
+        # short kernels' bf16 probabilities: two valid bf16 dataflows, about one rounding apart (measured 2.0e-3 forward)
+        ftol, gtol = 2 * ftol, 2 * gtol
     torch.manual_seed(2)
     ref = R.MultiheadAttention(D, H).eval()
     hip = P().MultiheadAttention(D, H, compute_dtype=mode)
@@ -246,7 +253,8 @@ def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("B,S,D,Hid,L,H,use_mask", [(2, 16, 64, 128, 2, 4, False), (1, 7, 32, 40, 1, 2, True), (8, 16, 512, 2048, 2, 8, False)])
+@pytest.mark.parametrize("B,S,D,Hid,L,H,use_mask", [(2, 16, 64, 128, 2, 4, False), (1, 7, 32, 40, 1, 2, True), (8, 16, 512, 2048, 2, 8, False),
+                                                    (2, 96, 64, 128, 2, 4, False), (2, 128, 128, 256, 1, 4, True)])          # T = 96, 128 tokens
 def test_transformer_encoder_matches_oracle(mode, B, S, D, Hid, L, H, use_mask):
     ftol, gtol = TOL[mode]
     torch.manual_seed(3)
@@ -270,6 +278,8 @@ def test_transformer_encoder_matches_oracle(mode, B, S, D, Hid, L, H, use_mask):
         yr = RB.encoder(orc, xr, mask)
         (yr * r.bfloat16().double()).sum().backward()
         ftol, gtol = 3 * L * ftol, 2 * L * gtol        # L layers = 6L rounding points in a row: the discrepancy compounds (oracle docstring)
+        if S > 64:
+            ftol, gtol = 2 * ftol, 2 * gtol            # fp32 attention core on bf16 operands (see the multi-head test)
     else:
         yr = ref(xr, mask)
         (yr * r).sum().backward()
@@ -313,6 +323,40 @@ def test_attention_dropout_statistics_and_backward_consistency():
     fd = ((out2 - out1) * r).sum().item() / eps
     an = (dv * dirv).sum().item()
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
+
+
+def test_long_sequence_attention_dropout_uses_one_mask_forward_and_backward():
+    """The same checks for the online-softmax kernels (S > 64): expectation preserved, same seed => same mask, and the backward kernels
+    regenerate the forward's mask (directional derivative w.r.t. v and w.r.t. q)."""
+    from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib, HYB_F32
+    B, S, D, H = 4, 96, 64, 4
+    torch.manual_seed(0)
+    q, k, v = (torch.rand(B, S, D, device="cuda") for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.query("hyb_attention_long_workspace", HYB_F32, B, S, D, H), dtype=torch.uint8, device="cuda")
+    lse = torch.empty(B * H, S, device="cuda")
+
+    def fwd(qq, vv, p, seed):
+        o = torch.empty_like(q)
+        lib.call("hyb_attention_long_fwd", HYB_F32, qq.data_ptr(), k.data_ptr(), vv.data_ptr(), D, None, o.data_ptr(), lse.data_ptr(), B, S, D, H, p, seed, None,
+                 ws.data_ptr(), ws.numel(), st)
+        return o
+    out0 = fwd(q, v, 0.0, 1)
+    acc = sum(fwd(q, v, 0.1, 1000 + s) for s in range(48)) / 48
+    assert rel(acc, out0) < 0.05
+    out1, out2 = fwd(q, v, 0.5, 7), fwd(q, v, 0.5, 7)
+    assert torch.equal(out1, out2) and not torch.equal(out1, out0)
+    r = torch.randn_like(q)
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    out1 = fwd(q, v, 0.5, 7)                                    # (lse of this call feeds the backward)
+    lib.call("hyb_attention_long_bwd", HYB_F32, q.data_ptr(), k.data_ptr(), v.data_ptr(), D, None, out1.data_ptr(), lse.data_ptr(), r.data_ptr(), dq.data_ptr(),
+             dk.data_ptr(), dv.data_ptr(), D, B, S, D, H, 0.5, 7, None, ws.data_ptr(), ws.numel(), st)
+    eps = 1e-2
+    for name, grad, pert in (("v", dv, lambda d: fwd(q, v + eps * d, 0.5, 7)), ("q", dq, lambda d: fwd(q + eps * d, v, 0.5, 7))):
+        dirn = torch.randn_like(q)
+        fd = ((pert(dirn) - out1) * r).sum().item() / eps
+        an = (grad * dirn).sum().item()
+        assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (name, fd, an)
 
 
 def test_layer_dropout_is_active_in_eval_like_the_reference():

@@ -550,6 +550,22 @@ namespace {
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8_c;
 
+// What the temporal encoder's attention() (TransformerEncoder.pyc src L49-62) has and FCT's nn.MultiheadAttention call does not: the mask
+// (masked_fill(mask == 0, -1e9) with the reference's head-replication order, quirk Q4: problem b*H + h reads mask[(b*H + h) mod B]) and the
+// dropout on the softmax weights (quirk Q5).  All-zero = neither.  The dropout multiplier of weight (problem, query, key) is a pure function
+// of (seed, index), so the backward kernels regenerate it; the normaliser and the saved log-sum-exp are those of the UNdropped softmax, and
+// delta = rowsum(dO * O) stays valid because O already contains the dropped weights.
+struct FlashExtra {
+    const float* mask;                   // [Bmask][L][L] or nullptr
+    int Bmask;
+    float p_drop, inv_keep;
+    unsigned long long seed;
+    const unsigned long long* seed_inc;  // device-side step counter added to the seed (graph replay), or nullptr
+};
+__device__ __forceinline__ unsigned long long flash_seed(const FlashExtra& ex) {
+    return ex.seed + ((ex.p_drop > 0.f && ex.seed_inc) ? *ex.seed_inc : 0ull);
+}
+
 // Feature-contraction step of the long-sequence kernels (S = K Q^T, dP = V dO^T).  fp32: 16 features per step = four 16x16x4 MFMAs with
 // 4 consecutive features per lane -- FCT's heads are 4..64 wide (padded to 8..64), and a 32-wide step would spend eight MFMAs on a
 // head of 8; bf16: the 32-wide single MFMA.
@@ -589,8 +605,9 @@ __device__ __forceinline__ void ff_row(F& f, const T* row, int f0, int dhp) {   
 
 template <typename T, int FWP = 0 /* 8: the 8-feature fp32 step (dhp == 8 only) */>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
-                                                           float* __restrict__ lse, int L, int H, int dhp, int ld, int ldi, float scale) {
+                                                           float* __restrict__ lse, int L, int H, int dhp, int ld, int ldi, float scale, FlashExtra ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned long long dseed = flash_seed(ex);
     T* Kimg = reinterpret_cast<T*>(smem_raw);                  // [64][ldi]
     T* Vimg = Kimg + 64 * ldi;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -639,7 +656,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float sv = (kb + kt * 16 + 4 * g + r < L) ? sT[kt][r] * scale : -INFINITY;
+                const int key = kb + kt * 16 + 4 * g + r;
+                float sv = (key < L) ? sT[kt][r] * scale : -INFINITY;
+                if (ex.mask && key < L && ex.mask[((long long)(blockIdx.y % ex.Bmask) * L + qrow) * L + key] == 0.f) sv = -1e9f;
                 sT[kt][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -652,7 +671,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
         for (int kt = 0; kt < 4; ++kt) {
             float pv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pv[r] = __expf(sT[kt][r] - mx); sum += pv[r]; }
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = __expf(sT[kt][r] - mx);
+                sum += pv[r];
+                if (ex.p_drop > 0.f)         // only the weights that multiply V are dropped
+                    pv[r] *= dropout_mult(dseed, ((unsigned long long)blockIdx.y * L + qrow) * L + (kb + kt * 16 + 4 * g + r), ex.p_drop, ex.inv_keep);
+            }
             acc_to_frag(P[kt], pv);
         }
         l = l * alpha + quad_lane_sum(sum);
@@ -1069,8 +1093,9 @@ template <typename T, int DTC, int FWP = 0>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                               const T* __restrict__ dout, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, T* __restrict__ dq, int L, int H, int dhp, int ld,
-                                                              int ldi, float scale) {
+                                                              int ldi, float scale, FlashExtra ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned long long dseed = flash_seed(ex);
     T* Kimg = reinterpret_cast<T*>(smem_raw);
     T* Vimg = Kimg + 64 * ldi;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1124,9 +1149,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
             float x[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool ok = kb + kt * 16 + 4 * g + r < L;
-                const float pv = ok ? __expf(sT[r] * scale - lse_q) : 0.f;
-                x[r] = pv * (dpT[r] - dl) * scale;
+                const int key = kb + kt * 16 + 4 * g + r;
+                const bool ok = key < L;
+                float sv = sT[r] * scale, dpv = dpT[r];
+                if (ex.mask && ok && ex.mask[((long long)(blockIdx.y % ex.Bmask) * L + qrow) * L + key] == 0.f) sv = -1e9f;
+                if (ex.p_drop > 0.f) dpv *= dropout_mult(dseed, ((unsigned long long)blockIdx.y * L + qrow) * L + key, ex.p_drop, ex.inv_keep);
+                const float pv = ok ? __expf(sv - lse_q) : 0.f;
+                x[r] = pv * (dpv - dl) * scale;
             }
             acc_to_frag(ds[kt], x);
         }
@@ -1154,8 +1183,9 @@ template <typename T, int DTC, int FWP = 0>
 __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                                const T* __restrict__ dout, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv, int L,
-                                                               int H, int dhp, int ld, int ldi, float scale) {
+                                                               int H, int dhp, int ld, int ldi, float scale, FlashExtra ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned long long dseed = flash_seed(ex);
     T* Qimg = reinterpret_cast<T*>(smem_raw);
     T* Gimg = Qimg + 64 * ldi;
     float* lseL = reinterpret_cast<float*>(Gimg + 64 * ldi);   // [64]
@@ -1216,8 +1246,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
             for (int r = 0; r < 4; ++r) {
                 const int ql = qt * 16 + 4 * g + r;
                 const bool ok = key < L && qb + ql < L;
-                pv[r] = ok ? __expf(sN[r] * scale - lseL[ql]) : 0.f;
-                ds[r] = pv[r] * (dpN[r] - delL[ql]) * scale;
+                float sv = sN[r] * scale, mult = 1.f;
+                if (ex.mask && ok && ex.mask[((long long)(blockIdx.y % ex.Bmask) * L + qb + ql) * L + key] == 0.f) sv = -1e9f;
+                if (ex.p_drop > 0.f && ok) mult = dropout_mult(dseed, ((unsigned long long)blockIdx.y * L + qb + ql) * L + key, ex.p_drop, ex.inv_keep);
+                const float pu = ok ? __expf(sv - lseL[ql]) : 0.f;                 // undropped softmax weight
+                ds[r] = pu * (dpN[r] * mult - delL[ql]) * scale;
+                pv[r] = pu * mult;                                                 // the weight that multiplied V
             }
             Frag16<T> dsF, pF;
             acc_to_frag(dsF, ds);
@@ -1247,8 +1281,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
 }  // namespace
 
 // Internal (fct.hip): out = softmax(q k^T * scale) v per (image, head), L tokens, heads of padded width dhp at stride ld
-int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
-                            float scale, hipStream_t st, int dh_true) {
+static int flash_fwd_impl(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
+                          float scale, hipStream_t st, int dh_true, const FlashExtra& ex) {
     if (!q || !k || !v || !out || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 || dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535) return HYB_E_ARG;
     static const int f4_env = getenv("HYB_FLASH_FWD4") ? atoi(getenv("HYB_FLASH_FWD4")) : 1;
     if (dtype == HYB_F32 && f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 8 && L >= 1024) {
@@ -1268,18 +1302,18 @@ int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void*
     const dim3 grid(hyb_cdiv(L, 64), N * H);
     if (dtype == HYB_F32) {
         if (lds > 64 * 1024) { static HybAttrOnce once; if (int e = hyb_set_lds_attr(once, (const void*)flash_fwd_kernel<float>, 160 * 1024)) return e; }
-        if (dhp == 8) hipLaunchKernelGGL((flash_fwd_kernel<float, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
-        else hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale);
+        if (dhp == 8) hipLaunchKernelGGL((flash_fwd_kernel<float, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale, ex);
+        else hipLaunchKernelGGL(flash_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, lse, L, H, dhp, ld, ldi, scale, ex);
     } else if (dtype == HYB_BF16) {
-        hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, L, H, dhp, ld, ldi, scale);
+        hipLaunchKernelGGL(flash_fwd_kernel<bf16>, grid, dim3(256), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, L, H, dhp, ld, ldi, scale, ex);
     } else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
 }
 
 // Internal (fct_bwd.hip): gradients of the long-sequence attention core.  lse from the forward pass; delta_ws: N*H*L floats of scratch.
-int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
-                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st, int dh_true) {
+static int flash_bwd_impl(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
+                          void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st, int dh_true, const FlashExtra& ex) {
     if (!q || !k || !v || !o || !dout || !lse || !delta_ws || !dq || !dk || !dv || N < 1 || L < 1 || H < 1 || dhp < 8 || dhp % 8 != 0 ||
         dhp > 16 * MAXDT || ld % 8 != 0 || (long long)N * H > 65535 || dtype != HYB_F32) return HYB_E_ARG;      // fp32 only so far (FCT runs in fp32)
     const int es = 4;
@@ -1287,7 +1321,11 @@ int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void*
     if ((bytes / 32) % 2 == 0) bytes += 32;
     const int ldi = bytes / es;
     const size_t lds = (size_t)2 * 64 * ldi * es + 2 * 64 * sizeof(float);
-    if (lds > 64 * 1024) return HYB_E_ARG;                       // 128-wide fp32 heads: 2 x 64 x 136 x 4 B = 68 KiB; FCT's widest head is 64
+    if (lds > 64 * 1024) {                                       // 128-wide fp32 heads (the temporal encoder's long sequences): 2 x 64 x 136 x 4 B = 68 KiB
+        static HybAttrOnce once_dq, once_dkv;
+        if (int e = hyb_set_lds_attr(once_dq, (const void*)flash_bwd_dq_kernel<float, 8>, 160 * 1024)) return e;
+        if (int e = hyb_set_lds_attr(once_dkv, (const void*)flash_bwd_dkv_kernel<float, 8>, 160 * 1024)) return e;
+    }
     const long long nq = (long long)N * H * L;
     hipLaunchKernelGGL(flash_delta_kernel<float>, dim3(hyb_cdiv(nq, 256)), dim3(256), 0, st, (const float*)o, (const float*)dout, delta_ws, N, L, H, dhp, ld);
     static const int f4_env = getenv("HYB_FLASH_BWD4") ? atoi(getenv("HYB_FLASH_BWD4")) : 1;
@@ -1310,17 +1348,128 @@ int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void*
     const dim3 grid(hyb_cdiv(L, 64), N * H);
 #define FLASH_BWD(DTC_) do { \
         hipLaunchKernelGGL((flash_bwd_dq_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \
-                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale); \
+                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale, ex); \
         hipLaunchKernelGGL((flash_bwd_dkv_kernel<float, DTC_>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, \
-                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale); } while (0)
+                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale, ex); } while (0)
     const int DT = (dhp + 15) / 16;
     if (dhp == 8) {
         hipLaunchKernelGGL((flash_bwd_dq_kernel<float, 1, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
-                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale);
+                           (const float*)delta_ws, (float*)dq, L, H, dhp, ld, ldi, scale, ex);
         hipLaunchKernelGGL((flash_bwd_dkv_kernel<float, 1, 8>), grid, dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
-                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale);
+                           (const float*)delta_ws, (float*)dk, (float*)dv, L, H, dhp, ld, ldi, scale, ex);
     } else if (DT <= 1) FLASH_BWD(1); else if (DT <= 2) FLASH_BWD(2); else if (DT <= 4) FLASH_BWD(4); else FLASH_BWD(8);
 #undef FLASH_BWD
     HYB_LAUNCH_CHECK();
     return 0;
+}
+
+// Internal (fct.hip / fct_bwd.hip): FCT's nn.MultiheadAttention core -- no mask, no dropout
+int hyb_flash_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int N, int L, int H, int dhp, int ld,
+                            float scale, hipStream_t st, int dh_true) {
+    return flash_fwd_impl(dtype, q, k, v, out, lse, N, L, H, dhp, ld, scale, st, dh_true, FlashExtra{});
+}
+int hyb_flash_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta_ws,
+                            void* dq, void* dk, void* dv, int N, int L, int H, int dhp, int ld, float scale, hipStream_t st, int dh_true) {
+    return flash_bwd_impl(dtype, q, k, v, o, dout, lse, delta_ws, dq, dk, dv, N, L, H, dhp, ld, scale, st, dh_true, FlashExtra{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MultiheadAttention.attention (TransformerEncoder.pyc src L49-62) for sequences of ANY length: the reference has no limit on S, the
+// register-resident kernels above hold at most 64 keys per query.  Longer sequences take the online-softmax kernels with the reference's
+// scale (1/sqrt(input_dim), quirk Q1), mask (Q4) and attention-weight dropout (Q5).  The core runs on fp32 operands: a bf16 caller's
+// q, k, v (and, backward, the saved output and its gradient) are widened into the workspace and the results rounded once on the way out.
+// q, k, v: [B*S] rows at stride ld_qkv elements (D for separate tensors, 3 D for the encoder's packed q|k|v), head h = features [h*dh, (h+1)*dh).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename TS, typename TD>
+__global__ void cast_rows_kernel(const TS* __restrict__ src, long long lds, TD* __restrict__ dst, long long ldd, int M, int D) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * D) return;
+    const long long r = i / D, c = i - r * D;
+    dst[r * ldd + c] = from_f32<TD>(to_f32<TS>(src[r * lds + c]));
+}
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline bool long_dims_ok(int B, int S, int D, int H) {
+    return B > 0 && S > 0 && D > 0 && H > 0 && D % H == 0 && (D / H) % 8 == 0 && D / H <= 16 * MAXDT && (long long)B * H <= 65535;
+}
+}  // namespace
+
+extern "C" size_t hyb_attention_long_workspace(int dtype, int B, int S, int D, int H) {
+    (void)dtype;
+    if (!long_dims_ok(B, S, D, H)) return 0;
+    const size_t M = (size_t)B * S;
+    return al256((size_t)B * H * S * sizeof(float)) + 8 * al256(M * D * sizeof(float));     // delta + q, k, v, out, dout, dq, dk, dv as dense fp32 [M][D]
+}
+
+namespace {
+template <typename T>
+int long_fwd_t(const T* q, const T* k, const T* v, int ld_qkv, T* out, float* lse, int B, int S, int D, int H, const FlashExtra& ex, char* ws, hipStream_t st) {
+    const int M = B * S, dh = D / H;
+    const float scale = 1.0f / sqrtf((float)D);                                // quirk Q1: sqrt(input_dim), not sqrt(head width)
+    if (sizeof(T) == 4 && ld_qkv == D) return flash_fwd_impl(HYB_F32, q, k, v, out, lse, B, S, H, dh, D, scale, st, 0, ex);
+    // the kernels address q, k, v and out with one row stride: packed q|k|v (stride 3 D) and bf16 operands go through dense fp32 copies
+    char* w = ws + al256((size_t)B * H * S * sizeof(float));
+    const size_t one = al256((size_t)M * D * sizeof(float));
+    float* f[4];
+    for (int i = 0; i < 4; ++i) f[i] = (float*)(w + i * one);
+    const dim3 g(hyb_cdiv((long long)M * D, 256));
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, q, (long long)ld_qkv, f[0], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, k, (long long)ld_qkv, f[1], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, v, (long long)ld_qkv, f[2], (long long)D, M, D);
+    if (int rc = flash_fwd_impl(HYB_F32, f[0], f[1], f[2], f[3], lse, B, S, H, dh, D, scale, st, 0, ex)) return rc;
+    hipLaunchKernelGGL((cast_rows_kernel<float, T>), g, dim3(256), 0, st, (const float*)f[3], (long long)D, out, (long long)D, M, D);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int long_bwd_t(const T* q, const T* k, const T* v, int ld_qkv, const T* out, const float* lse, const T* dout, T* dq, T* dk, T* dv, int ld_d, int B, int S,
+               int D, int H, const FlashExtra& ex, char* ws, hipStream_t st) {
+    const int M = B * S, dh = D / H;
+    const float scale = 1.0f / sqrtf((float)D);
+    float* delta = (float*)ws;
+    if (sizeof(T) == 4 && ld_qkv == D && ld_d == D)
+        return flash_bwd_impl(HYB_F32, q, k, v, out, dout, lse, delta, dq, dk, dv, B, S, H, dh, D, scale, st, 0, ex);
+    char* w = ws + al256((size_t)B * H * S * sizeof(float));
+    const size_t one = al256((size_t)M * D * sizeof(float));
+    float* f[8];
+    for (int i = 0; i < 8; ++i) f[i] = (float*)(w + i * one);
+    const dim3 g(hyb_cdiv((long long)M * D, 256));
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, q, (long long)ld_qkv, f[0], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, k, (long long)ld_qkv, f[1], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, v, (long long)ld_qkv, f[2], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, out, (long long)D, f[3], (long long)D, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<T, float>), g, dim3(256), 0, st, dout, (long long)D, f[4], (long long)D, M, D);
+    if (int rc = flash_bwd_impl(HYB_F32, f[0], f[1], f[2], f[3], f[4], lse, delta, f[5], f[6], f[7], B, S, H, dh, D, scale, st, 0, ex)) return rc;
+    hipLaunchKernelGGL((cast_rows_kernel<float, T>), g, dim3(256), 0, st, (const float*)f[5], (long long)D, dq, (long long)ld_d, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<float, T>), g, dim3(256), 0, st, (const float*)f[6], (long long)D, dk, (long long)ld_d, M, D);
+    hipLaunchKernelGGL((cast_rows_kernel<float, T>), g, dim3(256), 0, st, (const float*)f[7], (long long)D, dv, (long long)ld_d, M, D);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" int hyb_attention_long_fwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const float* mask, void* out, float* lse, int B,
+                                      int S, int D, int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(q && k && v && out && lse && workspace && long_dims_ok(B, S, D, H) && ld_qkv >= D && ld_qkv % 8 == 0 && p_drop >= 0.f && p_drop < 1.f);
+    HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
+    if (workspace_bytes < hyb_attention_long_workspace(dtype, B, S, D, H)) return HYB_E_WORKSPACE;
+    const FlashExtra ex{mask, B, p_drop, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed, seed_inc};
+    if (dtype == HYB_F32) return long_fwd_t<float>((const float*)q, (const float*)k, (const float*)v, ld_qkv, (float*)out, lse, B, S, D, H, ex, (char*)workspace, (hipStream_t)stream);
+    return long_fwd_t<bf16>((const bf16*)q, (const bf16*)k, (const bf16*)v, ld_qkv, (bf16*)out, lse, B, S, D, H, ex, (char*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int hyb_attention_long_bwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const float* mask, const void* out, const float* lse,
+                                      const void* dout, void* dq, void* dk, void* dv, int ld_d, int B, int S, int D, int H, float p_drop,
+                                      unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(q && k && v && out && lse && dout && dq && dk && dv && workspace && long_dims_ok(B, S, D, H) && ld_qkv >= D && ld_qkv % 8 == 0 &&
+                  ld_d >= D && ld_d % 8 == 0 && p_drop >= 0.f && p_drop < 1.f);
+    HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
+    if (workspace_bytes < hyb_attention_long_workspace(dtype, B, S, D, H)) return HYB_E_WORKSPACE;
+    const FlashExtra ex{mask, B, p_drop, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed, seed_inc};
+    if (dtype == HYB_F32)
+        return long_bwd_t<float>((const float*)q, (const float*)k, (const float*)v, ld_qkv, (const float*)out, lse, (const float*)dout, (float*)dq, (float*)dk,
+                                 (float*)dv, ld_d, B, S, D, H, ex, (char*)workspace, (hipStream_t)stream);
+    return long_bwd_t<bf16>((const bf16*)q, (const bf16*)k, (const bf16*)v, ld_qkv, (const bf16*)out, lse, (const bf16*)dout, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d,
+                            B, S, D, H, ex, (char*)workspace, (hipStream_t)stream);
 }

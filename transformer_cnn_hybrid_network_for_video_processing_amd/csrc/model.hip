@@ -27,6 +27,7 @@ int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void
                              unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
 int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
                              int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
+extern "C" size_t hyb_attention_long_workspace(int dtype, int B, int S, int D, int H);
 int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
                       float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -54,7 +55,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 #define HYB_HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 struct EncLayout {       // byte offsets inside `saved` for one layer, plus per-layer stride
-    size_t x_in, qkv, probs, attn, o, st1, x1, hmid, f, st2, layer_bytes;
+    size_t x_in, qkv, probs, attn, o, st1, x1, hmid, f, st2, long_ws, long_ws_bytes, layer_bytes;
     size_t wc[6], wt[6];   // T copies (plain / transposed) of Wq, Wk, Wv, Wo, W1, W2, converted once per forward;
                            // wt[0..2] are column blocks of ONE [D][3D] matrix (K-concatenated dX of the Q, K, V projections)
 };
@@ -74,6 +75,10 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     L.hmid = take(M * Hid * es);
     L.f = take(M * D * es);
     L.st2 = take(2 * M * 4);
+    // more than 64 tokens per clip: attention() goes through hyb_attention_long_* (attention.hip), whose scratch (dense fp32 copies of the
+    // packed q|k|v, delta) lives here, per layer, in the caller's saved blob: the forward entry point has no workspace argument
+    L.long_ws_bytes = S > 64 ? hyb_attention_long_workspace(dtype, B, S, D, H) : 0;
+    L.long_ws = take(L.long_ws_bytes);
     const size_t wsz[6] = {(size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)Hid * D, (size_t)D * Hid};
     for (int i = 0; i < 6; ++i) L.wc[i] = take(wsz[i] * es);
     L.wt[0] = take(3 * wsz[0] * es);
@@ -202,7 +207,8 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
     const size_t big = (size_t)(Hid > D ? Hid : D);
     // (the buffers a layer's weight gradients read -- g1, dqkv, dh, g1b, LayerNorm partial rows -- exist twice: with the side stream
     // the gradients of layer i are still being formed while layer i-1 runs)
-    return 12 * align256(M * D * es) + 4 * align256(M * big * es) + 2 * align256((size_t)2 * 32 * 2 * D * sizeof(float));
+    return 12 * align256(M * D * es) + 4 * align256(M * big * es) + 2 * align256((size_t)2 * 32 * 2 * D * sizeof(float)) +
+           (S > 64 ? align256(hyb_attention_long_workspace(dtype, B, S, D, H)) : 0);      // scratch of the long-sequence attention backward
 }
 
 extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
@@ -248,6 +254,11 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
         const float* bs[3] = {P[1], P[3], P[5]};
         void* ys[3] = {base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es};
         HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, 3 * D, 1, 0, st));                           // src L69-70
+        if (S > 64)
+            HYB_TRY(hyb_attention_long_fwd(dtype, base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es, 3 * D, mask,
+                                           base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p, attn_seed(seed, i), seed_inc,
+                                           base + lay.long_ws, lay.long_ws_bytes, st));
+        else
         HYB_TRY(hyb_attention_fwd_packed(dtype, base + lay.qkv, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p,
                                          attn_seed(seed, i), seed_inc, st));                                          // src L73-84
         { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
@@ -296,6 +307,7 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
             set[j].lnpart = (float*)q; q += lnb;    // LayerNorm affine-gradient partial rows of the layer's two calls
         }
     }
+    void* const long_ws = ws + 12 * md + 4 * big + 2 * lnb;       // S > 64 only (hyb_encoder_workspace_bytes)
     // Off the dX chain: the layer's LayerNorm-affine reduce and its six weight (+ bias) gradients.  While the stream is being captured
     // they go to the side stream (a parallel graph branch beside the next layer's latency-bound chain); otherwise they stay in line.
     HybSide* side = hyb_side_for(st);
@@ -328,6 +340,12 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         { const void* A_[1] = {b.g1b}; const void* B_[1] = {base + lay.wt[3]}; void* C_[1] = {g4};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, D, D, D, D, 0, 0, st)); }
         // attention core: d(q|k|v) packed [M][3D]
+        if (S > 64)
+            HYB_TRY(hyb_attention_long_bwd(dtype, base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es, 3 * D, mask,
+                                           base + lay.attn, (const float*)(base + lay.probs), g4, b.dqkv, (char*)b.dqkv + (size_t)D * es,
+                                           (char*)b.dqkv + 2 * (size_t)D * es, 3 * D, B, S, D, H, attn_p, attn_seed(seed, i), seed_inc,
+                                           long_ws, lay.long_ws_bytes, st));
+        else
         HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, b.dqkv, B, S, D, H, attn_p,
                                          attn_seed(seed, i), seed_inc, st));
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM

@@ -402,8 +402,8 @@ def token(x, weight, bias, dt):
 # TransformerEncoder.forward (all layers) -- TransformerEncoder.pyc src L110-126
 # ---------------------------------------------------------------------------------------------
 def _check_attention_limits(S, D, H):
-    if S > 64:
-        raise RuntimeError(f"temporal attention kernel supports T <= 64 tokens per clip (got {S})")
+    # (no limit on S: up to 64 tokens per clip the register-resident kernels, beyond that the online-softmax kernels -- hyb_attention_long_*;
+    # the reference's attention(), TransformerEncoder.pyc src L49-62, has none either)
     if D % H != 0 or (D // H) % 8 != 0 or D // H > 128:
         raise RuntimeError(f"temporal attention kernel supports head widths that are multiples of 8 up to 128 (got {D}/{H})")
 
@@ -478,8 +478,13 @@ def mha_op(q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Optional[Tensor], par
     st = _stream()
     for src, W_, b_, dst in ((q_in, ps[0], ps[1], q), (k_in, ps[2], ps[3], k), (v_in, ps[4], ps[5], v)):
         lib.call("hyb_linear_fwd", dt, src.data_ptr(), D, W_.data_ptr(), b_.data_ptr(), dst.data_ptr(), M, D, D, 1, st)
-    lib.call("hyb_attention_fwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), _opt_ptr(mask), a.data_ptr(),
-             probs.data_ptr(), B, S, D, H, float(p_drop), seed, st)
+    if S > 64:           # probs then holds the log-sum-exp per (clip, head, query) in its first B*H*S floats
+        ws = _ws(_query("hyb_attention_long_workspace", dt, B, S, D, H), dev)
+        lib.call("hyb_attention_long_fwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), D, _opt_ptr(mask), a.data_ptr(), probs.data_ptr(), B, S, D, H,
+                 float(p_drop), seed, None, ws.data_ptr(), ws.numel(), st)
+    else:
+        lib.call("hyb_attention_fwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), _opt_ptr(mask), a.data_ptr(),
+                 probs.data_ptr(), B, S, D, H, float(p_drop), seed, st)
     lib.call("hyb_linear_fwd", dt, a.data_ptr(), D, ps[6].data_ptr(), ps[7].data_ptr(), out.data_ptr(), M, D, D, 0, st)
     return out, q, k, v, a, probs
 
@@ -504,8 +509,13 @@ def mha_bwd_op(dout: Tensor, q_in: Tensor, k_in: Tensor, v_in: Tensor, mask: Opt
     ws = _ws(M * D * 4, dev)
     lib.call("hyb_linear_bwd", dt, a.data_ptr(), D, ps[6].data_ptr(), None, dout.data_ptr(), da.data_ptr(), 0, grads[6].data_ptr(),
              grads[7].data_ptr(), M, D, D, 0, None, 0, st)
-    lib.call("hyb_attention_bwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), _opt_ptr(mask), probs.data_ptr(), da.data_ptr(), dq.data_ptr(),
-             dk.data_ptr(), dv.data_ptr(), B, S, D, H, float(p_drop), seed, st)
+    if S > 64:
+        lws = _ws(_query("hyb_attention_long_workspace", dt, B, S, D, H), dev)
+        lib.call("hyb_attention_long_bwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), D, _opt_ptr(mask), a.data_ptr(), probs.data_ptr(), da.data_ptr(),
+                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), D, B, S, D, H, float(p_drop), seed, None, lws.data_ptr(), lws.numel(), st)
+    else:
+        lib.call("hyb_attention_bwd", dt, q.data_ptr(), k.data_ptr(), v.data_ptr(), _opt_ptr(mask), probs.data_ptr(), da.data_ptr(), dq.data_ptr(),
+                 dk.data_ptr(), dv.data_ptr(), B, S, D, H, float(p_drop), seed, st)
     for src, y, dy, dsrc, iw in ((q_in, q, dq, dqi, 0), (k_in, k, dk, dki, 2), (v_in, v, dv, dvi, 4)):
         lib.call("hyb_linear_bwd", dt, src.contiguous().data_ptr(), D, ps[iw].data_ptr(), y.data_ptr(), dy.data_ptr(), dsrc.data_ptr(), 0,
                  grads[iw].data_ptr(), grads[iw + 1].data_ptr(), M, D, D, 1, ws.data_ptr(), ws.numel(), st)
