@@ -48,6 +48,24 @@ __global__ void persistent_kernel(Bar b, unsigned* tokens, unsigned* errors, int
     }
 }
 
+// Clip-local variant (round 3): 256 workgroups in 8 groups of 32 = blockIdx % 8 (workgroups are dealt round-robin over the 8 XCDs, so a
+// group shares an XCD and its L2); each group synchronises on ITS OWN counter (one 256-byte line per group) -- the structure of a persistent
+// encoder layer in which a clip's 32 workgroups only ever wait for each other (attention never crosses clips).  All 8 groups run at once.
+__global__ void persistent_local_kernel(unsigned* counters, unsigned* abort_flag, unsigned* tokens, unsigned* errors, int nb, int with_data) {
+    unsigned target = 0;
+    const unsigned grp = blockIdx.x & 7, idx = blockIdx.x >> 3, gsz = gridDim.x >> 3;
+    Bar b{counters + grp * 64, abort_flag};
+    for (int i = 0; i < nb; ++i) {
+        if (with_data && threadIdx.x == 0) tokens[blockIdx.x * 32] = (unsigned)(i + 1);
+        if (!grid_barrier(b, target, gsz)) return;
+        if (with_data && threadIdx.x == 0) {
+            unsigned nbr = ((idx + gsz / 2 + 1) % gsz) * 8 + grp;                   // a workgroup of the same group
+            unsigned v = __hip_atomic_load(&tokens[nbr * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != (unsigned)(i + 1) && v != (unsigned)(i + 2)) atomicAdd(errors, 1u);
+        }
+    }
+}
+
 __global__ void tiny_kernel(unsigned* tokens, int i) {
     if (threadIdx.x == 0) {
         unsigned nbr = (blockIdx.x + gridDim.x / 2 + 1) % gridDim.x;
@@ -84,6 +102,29 @@ int main() {
                first ? "" : ",\n", threads, nwg, with_data, best * 1000.f / NB, herr, habort);
         first = false;
         if (habort) { printf("]}\n"); return 2; }
+    }
+    printf("\n],\n\"clip_local_barriers\": [\n");
+    {
+        unsigned* counters; CK(hipMalloc(&counters, 8 * 64 * 4));
+        first = true;
+        for (int with_data : {0, 1}) {
+            float best = 1e30f; unsigned herr = 0, habort = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemsetAsync(counters, 0, 8 * 64 * 4, st)); CK(hipMemsetAsync(abortf, 0, 4, st)); CK(hipMemsetAsync(errors, 0, 4, st));
+                CK(hipEventRecord(e0, st));
+                persistent_local_kernel<<<256, 256, 0, st>>>(counters, abortf, tokens, errors, NB, with_data);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+                CK(hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&habort, abortf, 4, hipMemcpyDeviceToHost));
+                if (habort) break;
+            }
+            printf("%s {\"workgroups\": 256, \"groups\": 8, \"group_size\": 32, \"with_data\": %d, \"us_per_barrier\": %.3f, \"stale_reads\": %u, \"aborted\": %u}",
+                   first ? "" : ",\n", with_data, best * 1000.f / NB, herr, habort);
+            first = false;
+            if (habort) { printf("]}\n"); return 2; }
+        }
     }
     printf("\n],\n\"launch_boundaries\": [\n");
     first = true;

@@ -17,7 +17,9 @@ SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip
 # and every accumulator value is consumed by vector instructions, which cannot read AGPRs (one v_accvgpr_read per value otherwise).
 # conv_wgrad.hip: no SLP vectorisation -- it packs the producers' fp32 arithmetic into v_pk_fma_f32 / v_pk_mul_f32, which issue slower
 # than the scalar pairs next to the consumers' MFMAs (measured: fused weight gradient 82.6 -> 78.9 us at stage 4, profiles/r03_wgrad_ablation.txt).
-FILE_FLAGS = {"conv_first_wave.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_wgrad.hip": ["-fno-slp-vectorize"]}
+# conv_v2.hip: the same flag, same reason (epilogue arithmetic beside the MFMA stream; -4 us per step same-box A/B); bn_pool.hip, a pure streaming
+# file, LOSES 14 us per step with it and keeps the default.
+FILE_FLAGS = {"conv_first_wave.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_wgrad.hip": ["-fno-slp-vectorize"], "conv_v2.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -1,6 +1,7 @@
 // BatchNorm2d (UNet.py:59) + ReLU (UNet.py:60) + MaxPool2d(2,2) (UNet.py:13) on NHWC activations,
 // forward and backward, plus the global-average-pool frame token and layout/cast helpers.
 // All of these are HBM-bound streaming kernels: 8 channels (16 B of bf16) per lane, channel-fastest.
+#include <stdlib.h>
 #include "hyb_common.h"
 
 namespace {
@@ -249,13 +250,41 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce_pooled_kernel(con
                 }
             }
         }
+        // Block partial row without the old 16-float-stride LDS scatter (89 % of its LDS cycles were bank conflicts, and with three
+        // groups per thread at stage 4 the epilogue WAS the kernel): lanes of a wave that own the same octet (lane = oc mod OCT) add up
+        // through cross-lane steps first -- a fixed butterfly, so the sum order is fixed -- and only OCT lanes per wave touch LDS.
+        if (OCT <= 32 && (OCT & (OCT - 1)) == 0 && nthr == 256) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            red[threadIdx.x * 16 + j] = a1[j];
-            red[threadIdx.x * 16 + 8 + j] = a2[j];
+            for (int j = 0; j < 8; ++j) {
+                for (int o = 32; o >= OCT; o >>= 1) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
+            }
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            if (lane < OCT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                   // red[wave][which][j][oc]: consecutive lanes -> consecutive banks
+                    red[((wv * 2 + 0) * 8 + j) * OCT + lane] = a1[j];
+                    red[((wv * 2 + 1) * 8 + j) * OCT + lane] = a2[j];
+                }
+            }
+                    } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[threadIdx.x * 16 + j] = a1[j];
+                red[threadIdx.x * 16 + 8 + j] = a2[j];
+            }
         }
     }
     __syncthreads();
+    if (OCT <= 32 && (OCT & (OCT - 1)) == 0 && nthr == 256) {
+        for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) {
+            const int which = i / Cop, ch = i % Cop, o8 = ch >> 3, j = ch & 7;
+            float acc = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) acc += red[((wv * 2 + which) * 8 + j) * OCT + o8];
+            sums[(long long)blockIdx.x * 2 * Cop + i] = acc;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 2 * Cop; i += blockDim.x) {
         const int which = i / Cop, ch = i % Cop, o8 = ch >> 3, j = ch & 7;
         float acc = 0.f;
@@ -507,7 +536,10 @@ extern "C" int hyb_bn_relu_pool_bwd_reduce(int dtype, const void* dpooled, const
                                            float* sums, float* partials, float* dgamma, float* dbeta, int N, int H, int W, int Co, int Cop,
                                            void* stream) {
     HYB_CHECK_ARG(dpooled && y && ss && mi && sums && partials && N > 0 && H >= 2 && W >= 2 && Cop % 32 == 0 && Cop > 0 && Cop / 8 <= 256);
-    const int grid = row_grid(N * (H / 2));
+    // (the pooled form streams flat groups, not rows: one block per CU (measured 26 / 17.5 / 15.8 us at 1024 / 512 / 256 blocks) with 4 x 2 loads in flight per lane cover the memory latency, and
+    // fewer blocks mean fewer partial rows for the second launch)
+    static const int pooled_grid = getenv("HYB_BN_REDUCE_WGS") ? atoi(getenv("HYB_BN_REDUCE_WGS")) : 256;
+    const int grid = (pooled && pooled_grid >= 1 && pooled_grid <= BN_MAX_ROWBLOCKS) ? (N * (H / 2) < pooled_grid ? N * (H / 2) : pooled_grid) : row_grid(N * (H / 2));
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 256 * 16 * sizeof(float);
     if (pooled) {
