@@ -24,6 +24,9 @@
  *   - `dtype` selects the storage/MFMA-operand type T of activations:
  *       HYB_F32  : fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32; the parity gate)
  *       HYB_BF16 : bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate/statistics
+ *     A second build of the SAME sources and the SAME ABI, libhybrid_hip_x3.so (-DHYB_F32_X3), gives HYB_F32 a third meaning: fp32
+ *     storage, every contraction product from three bf16 MFMAs on two-term splits (x = hi + lo; csrc/hyb_common.h) -- within 1e-5 of the
+ *     exact mode at 1.8 x its speed.  The Python host side selects it with compute_dtype="bf16x3" (_lib.py routes by library).
  *     Parameters (weights, biases, BN/LN affine, running stats) and parameter
  *     gradients are always fp32.
  *   - internal activation layout is NHWC with the channel count padded to a multiple

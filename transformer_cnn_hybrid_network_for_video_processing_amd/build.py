@@ -10,7 +10,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhybrid_hip.so")
 LIB_X3 = os.path.join(PKG, "libhybrid_hip_x3.so")     # the same sources with -DHYB_F32_X3: fp32 storage, split-bf16 products (hyb_common.h)
-SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "side.hip", "fct.hip", "fct_bwd.hip", "bn2d.hip", "optim.hip"]
+SOURCES = ["conv_fwd.hip", "conv_v2.hip", "conv_first.hip", "conv_first_wave.hip", "conv_wgrad.hip", "bn_pool.hip", "linear.hip", "attention.hip", "layernorm.hip", "model.hip", "fused.hip", "fct.hip", "fct_bwd.hip", "bn2d.hip", "optim.hip"]
 
 
 # Per-file compiler flags.  conv_first_wave.hip: MFMA results in VGPRs instead of AGPRs -- its kernels are bound by VALU instruction issue

@@ -258,11 +258,3 @@ __device__ __forceinline__ bool rows_reduce_1024(const float* __restrict__ part,
     sum_out = s;
     return true;
 }
-
-// ---------------------------------------------------------------------------------------
-// side.hip: the library's side stream (see there).  hyb_side_for returns the current device's set only while `main` is being
-// captured into a graph, else nullptr (= stay on the caller's stream).
-// ---------------------------------------------------------------------------------------
-struct HybSide { hipStream_t s; hipEvent_t fork; hipEvent_t done[2]; };
-HybSide* hyb_side_for(hipStream_t main);
-

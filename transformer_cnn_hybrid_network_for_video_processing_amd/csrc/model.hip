@@ -205,8 +205,7 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const size_t M = (size_t)B * S;
     const size_t big = (size_t)(Hid > D ? Hid : D);
-    // (the buffers a layer's weight gradients read -- g1, dqkv, dh, g1b, LayerNorm partial rows -- exist twice: with the side stream
-    // the gradients of layer i are still being formed while layer i-1 runs)
+    // (the buffers a layer's weight gradients read -- g1, dqkv, dh, g1b, LayerNorm partial rows -- exist twice, one set per layer parity)
     return 12 * align256(M * D * es) + 4 * align256(M * big * es) + 2 * align256((size_t)2 * 32 * 2 * D * sizeof(float)) +
            (S > 64 ? align256(hyb_attention_long_workspace(dtype, B, S, D, H)) : 0);      // scratch of the long-sequence attention backward
 }
@@ -308,10 +307,8 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         }
     }
     void* const long_ws = ws + 12 * md + 4 * big + 2 * lnb;       // S > 64 only (hyb_encoder_workspace_bytes)
-    // Off the dX chain: the layer's LayerNorm-affine reduce and its six weight (+ bias) gradients.  While the stream is being captured
-    // they go to the side stream (a parallel graph branch beside the next layer's latency-bound chain); otherwise they stay in line.
-    HybSide* side = hyb_side_for(st);
-    bool pending[2] = {false, false};
+    // (The layer's weight-gradient launch is off the dX chain; issuing it as a parallel branch of the replayed graph was measured in
+    // round 2 and lost 4.7 % of the step -- every fork / join edge costs more than the 5 us kernel it hides -- so it stays in line.)
 
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
@@ -320,10 +317,6 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         float* const* G = grads + (size_t)i * 14;
         void* gx = (i == 0) ? dx : gin[i & 1];
         const Set& b = set[i & 1];
-        if (side && pending[i & 1]) {               // layer i+2's gradients still read this parity's buffers
-            HYB_HIP_TRY(hipStreamWaitEvent(st, side->done[i & 1], 0));
-            pending[i & 1] = false;
-        }
         // LN2 + residual + sqrt(.5) + dropout
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), b.g1, g2, 0, b.lnpart, M, D,
                                          (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, st));
@@ -351,12 +344,6 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM
         { const void* A_[1] = {b.dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }
-        hipStream_t ws_st = st;
-        if (side) {                                 // fork: everything the gradients read has been enqueued on `st`
-            HYB_HIP_TRY(hipEventRecord(side->fork, st));
-            HYB_HIP_TRY(hipStreamWaitEvent(side->s, side->fork, 0));
-            ws_st = side->s;
-        }
         // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches); the
         // layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients ride in the same launch
         {
@@ -368,13 +355,9 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
             float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
             const int N_[6] = {D, Hid, D, D, D, D}, K_[6] = {Hid, D, D, D, D, D};
             const int lddy_[6] = {D, Hid, D, 3 * D, 3 * D, 3 * D}, ldx_[6] = {Hid, D, D, D, D, D};
-            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, ws_st, b.lnpart, 2 * lnrows, D, G[12], G[13]));
+            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, b.lnpart, 2 * lnrows, D, G[12], G[13]));
         }
-        if (side) { HYB_HIP_TRY(hipEventRecord(side->done[i & 1], side->s)); pending[i & 1] = true; }
         gA = gx;
     }
-    if (side)                                       // join: the caller's stream continues after every gradient launch
-        for (int j = 0; j < 2; ++j)
-            if (pending[j]) HYB_HIP_TRY(hipStreamWaitEvent(st, side->done[j], 0));
     return 0;
 }
