@@ -3,16 +3,18 @@
 # the bench command for configs 2/4/5, the two PMC passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) of config 2, the
 # attention micro-benchmark, the FCT and Encoder_32K benches.  Output under gpurun_out/prof_<tag>/; scripts/publish_profiles.py copies the summaries.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $REPO
-python3 bench.py --steps 100 --warmup 10 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err          # the driver's command: headline + every extra leg
+python3 bench.py --steps 100 --warmup 10 --no-extra-legs > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python3 bench.py --eager --steps 100 --warmup 10 --no-cpu-baseline --no-roofline > $OUT/bench_c2_eager.json 2> $OUT/bench_c2_eager.err
 python3 bench.py --config 4 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python3 bench.py --config 5 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 python3 bench.py --dtype fp32 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
+python3 bench.py --dtype bf16x3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_bf16x3.json 2> $OUT/bench_bf16x3.err
 echo "bench lines done"
 python3 scripts/attn_microbench.py > $OUT/attention_microbench.json 2> $OUT/attention_microbench.err || true
 python3 scripts/fct_bench.py --cpu > $OUT/fct_bench.json 2> $OUT/fct_bench.err || true

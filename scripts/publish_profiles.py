@@ -9,7 +9,7 @@ tag = f"{rnd}_{state}"
 def cp(a, b):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b)); print(b)
-for name in ("c2", "c2_eager", "c4", "c5", "fp32"):
+for name in ("default", "c2", "c2_eager", "c4", "c5", "fp32", "bf16x3"):
     cp(f"bench_{name}.json", f"{tag}_bench_{name}.json")
 for c in (2, 4, 5):
     cp(f"kt_c{c}/kt_kernel_stats.csv", f"{tag}_kernel_stats_c{c}.csv")
