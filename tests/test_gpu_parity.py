@@ -100,6 +100,9 @@ def _stage_pair(ci, co, name, mode, seed=0):
                                          (256, 128, 1, 8, 8), (8, 16, 2, 10, 10), (96, 96, 1, 8, 12),
                                          (64, 64, 3, 30, 58), (128, 128, 2, 34, 62), (64, 192, 9, 18, 30), (32, 64, 3, 30, 58),
                                          (64, 64, 2, 29, 57), (32, 64, 1, 9, 30), (128, 128, 1, 7, 55), (64, 256, 2, 12, 28), (32, 128, 5, 3, 3),
+                                         # shapes the third-generation fused wgrad takes (64-channel blocks, 28 k columns, H % 4 == 0): full tiles + a half
+                                         # tile, two tile columns, several ci / co blocks, a run that ends inside an image
+                                         (64, 128, 2, 28, 28), (128, 256, 3, 8, 56), (64, 64, 2, 16, 84), (128, 64, 1, 56, 28), (192, 128, 5, 20, 28),
                                          # first-stage variants of the wave-private kernels: 1/2/4 input channels (generic channel loop), 64 output
                                          # channels (four channel tiles per wave), ragged 8x16 blocks (forward wave-private, backward block-level)
                                          (1, 32, 2, 16, 32), (4, 32, 1, 8, 16), (2, 64, 1, 24, 48), (3, 32, 2, 16, 20), (3, 64, 2, 8, 16),
