@@ -96,3 +96,48 @@ def test_graphed_step_accepts_new_batches():
         assert abs(ref - l1) < 1e-6 * max(1.0, abs(ref))
     finally:
         tr.close()
+
+
+def test_graphed_long_clip_steps_equal_eager_and_redraw_masks():
+    """Clips of more than 64 frames take the long-sequence attention kernels (hyb_attention_long_*): the captured step must still be
+    the eager step bit for bit (no dropout), and with attention-weight dropout every replay must draw fresh masks from the device
+    counter."""
+    crit = P().HybridCrossEntropyLoss()
+    T = 72
+
+    def setup(attn_p):
+        torch.manual_seed(0)
+        m = P().TransformerCNNHybrid(dropout=0.0, **KW).cuda().train()
+        for a in m.encoder.attention_layers:
+            a.dropoutLayer.p = attn_p
+        g = torch.Generator().manual_seed(5)
+        return m, torch.rand(2, T, 3, 32, 32, generator=g).cuda(), torch.randint(0, 8, (2,), generator=g).cuda()
+    K, WARM = 3, 1
+    m1, x, y = setup(0.0)
+    m2, _, _ = setup(0.0)
+    o1, o2 = P().HybridAdamW(m1.parameters(), lr=1e-3), P().HybridAdamW(m2.parameters(), lr=1e-3)
+    eager = []
+    for _ in range(WARM + K):
+        o1.zero_grad(set_to_none=True)
+        loss = crit(m1(x), y)
+        loss.backward()
+        o1.step()
+        eager.append(loss.item())
+    tr = P().GraphedTrainStep(m2, crit, o2, x, y, warmup=WARM)
+    try:
+        assert [tr.step().item() for _ in range(K)] == eager[WARM:]
+        for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(a, b), n
+    finally:
+        tr.close()
+    m3, x, y = setup(0.3)
+    o3 = P().HybridAdamW(m3.parameters(), lr=0.0, weight_decay=0.0)
+    for s in m3.modules():
+        if isinstance(s, torch.nn.BatchNorm2d):
+            s.momentum = 0.0
+    tr = P().GraphedTrainStep(m3, crit, o3, x, y, warmup=1)
+    try:
+        losses = [tr.step().item() for _ in range(4)]
+        assert len(set(losses)) == len(losses) and all(l == l for l in losses)
+    finally:
+        tr.close()
