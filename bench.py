@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fwd-bwd-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive leg (host uint8 clips fed through clips.ClipPipeline)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 --pmc child runs (use profiles/*_traffic.json)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short extra legs printed beside the headline (config 4 / 5, fp32 and bf16x3 "
                                                                  "modes, FCT, Encoder_32K, config-1 CPU baseline, the in-run bf16 logits check)")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python each step instead of replaying the captured hipGraphs "
@@ -548,6 +549,44 @@ def bf16_logits_check(dev):
     return out
 
 
+def live_traffic(kernel_name, timeout_s=150):
+    """HBM bytes per launch of `kernel_name`, MEASURED IN THIS RUN: two child runs of this script (3 eager steps each) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (counters only, separate passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
+    doubled: the gfx950 correction).  Returns (bytes, how) or (None, reason)."""
+    import csv, glob, shutil, tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hyb_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--eager",
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-fwd-bwd-only", "--no-pipeline", "--no-extra-legs"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "no counter_collection.csv"
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if row["Counter_Name"] == counter and kernel_name.split("<")[0] in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"]]
+            if kernel_name.startswith("wgrad_v2_kernel<"):      # template instances of one name: keep the block width asked for
+                want = kernel_name.split(",")[1].strip(" >")
+                v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                     if row["Counter_Name"] == counter and "wgrad_v2_kernel<" in row["Kernel_Name"] and f", {want}," in row["Kernel_Name"]]
+            if not v:
+                return None, f"kernel {kernel_name} not in the {counter} pass"
+            vals[counter] = sum(v) / len(v)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, (
+        "measured in this run: child runs of this script (3 eager steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate "
+        "passes); FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units, average over this kernel's launches")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -759,6 +798,12 @@ def main():
                     if t:
                         traffic, tsrc = t["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
                         break
+            if not args.no_live_traffic and args.dtype == "bf16" and args.config == 2 and is_cfg and not args.no_extra_legs:
+                lt, how = live_traffic(dom["name"])
+                if lt is not None:
+                    traffic, tsrc = lt, how
+                else:
+                    tsrc = (tsrc or "none") + f" [live PMC measurement unavailable: {how}]"
             out["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "launches_per_step": dom["launches_per_step"],
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": traffic, "traffic_source": tsrc, "ms": dom["ms"], "flops_per_launch": dom["flops"],
