@@ -608,6 +608,54 @@ int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, i
     return 0;
 }
 
+// The same for SEVERAL stages in one launch (internal; hyb_backbone_fwd): blockIdx.y = stage.  The weights do not depend on the
+// activations, so the whole backbone's packs can run before its first convolution (three 5 us launches fewer per step at config 2).
+struct PackMany { const float* w[16]; void* wp0[16]; void* wp1[16]; int Co[16], Ci[16], Cop[16], Cip[16]; };
+template <typename T>
+__global__ void pack_weight_many_kernel(PackMany a) {
+    const int s = blockIdx.y;
+    const long long count = (long long)a.Cop[s] * 9 * a.Cip[s];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * count) return;
+    const float* __restrict__ w = a.w[s];
+    const int Co = a.Co[s], Ci = a.Ci[s], Cop = a.Cop[s], Cip = a.Cip[s];
+    const bool second = i >= count;
+    const long long k = second ? i - count : i;
+    const int c32 = (int)(k % 32);
+    const int tap = (int)((k / 32) % 9);
+    float v = 0.f;
+    if (!second) {
+        const int chunk = (int)((k / 288) % (Cip / 32));
+        const int co = (int)(k / ((long long)9 * Cip));
+        const int ci = chunk * 32 + c32;
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
+        ((T*)a.wp0[s])[k] = from_f32<T>(v);
+    } else {
+        const int chunk = (int)((k / 288) % (Cop / 32));
+        const int ci = (int)(k / ((long long)9 * Cop));
+        const int co = chunk * 32 + c32;
+        if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
+        ((T*)a.wp1[s])[k] = from_f32<T>(v);
+    }
+}
+int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* const* wp0, void* const* wp1, const int* Co, const int* Ci, const int* Cop,
+                              const int* Cip, hipStream_t st) {
+    if (n < 1 || n > 16) return HYB_E_ARG;
+    PackMany a{};
+    long long maxc = 0;
+    for (int i = 0; i < n; ++i) {
+        a.w[i] = w[i]; a.wp0[i] = wp0[i]; a.wp1[i] = wp1[i]; a.Co[i] = Co[i]; a.Ci[i] = Ci[i]; a.Cop[i] = Cop[i]; a.Cip[i] = Cip[i];
+        const long long c = (long long)Cop[i] * 9 * Cip[i];
+        if (c > maxc) maxc = c;
+    }
+    const dim3 grid(hyb_cdiv(2 * maxc, 256), n);
+    if (dtype == HYB_F32) hipLaunchKernelGGL(pack_weight_many_kernel<float>, grid, dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16) hipLaunchKernelGGL(pack_weight_many_kernel<bf16>, grid, dim3(256), 0, st, a);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int hyb_conv_pack_weight(int dtype, int mode, const float* w, void* wp, int Co, int Ci, int Cop, int Cip, void* stream) {
     HYB_CHECK_ARG(w && wp && Co > 0 && Ci > 0 && Cop % 32 == 0 && Cop >= Co && mode >= 0 && mode <= 2);
     if (mode == 2) HYB_CHECK_ARG(Ci <= 3);

@@ -7,6 +7,13 @@
 #include "hyb_common.h"
 
 size_t hyb_encoder_xin_offset(int dtype, int B, int S, int D, int Hid, int H);
+int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
+                           int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
+                           float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream,
+                           const void* prepacked_fwd);
+int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* const* wp0, void* const* wp1, const int* Co, const int* Ci, const int* Cop,
+                              const int* Cip, hipStream_t st);
 
 namespace {
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -19,7 +26,11 @@ extern "C" size_t hyb_backbone_fwd_workspace(int dtype, int stages, const int* c
     if (stages < 1 || !channels) return 0;
     size_t b = 0;
     for (int s = 0; s < stages; ++s) b = smax(b, hyb_convstage_fwd_workspace(dtype, s == 0, s == 0 ? 0 : padc(channels[s]), padc(channels[s + 1])));
-    return al256(b);
+    // + one forward weight pack per non-first stage: all of them are written by ONE launch before the first convolution
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    size_t packs = 0;
+    for (int s = 1; s < stages; ++s) packs += al256((size_t)hyb_conv_packed_elems(0, padc(channels[s]), padc(channels[s + 1])) * es);
+    return al256(b) + packs;
 }
 
 extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params, int training,
@@ -30,15 +41,38 @@ extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, cons
     if (workspace_bytes < hyb_backbone_fwd_workspace(dtype, stages, channels)) return HYB_E_WORKSPACE;
     const void* in = x;
     int h = H, w = W;
+    // weight packs of stages 1.. (forward layout into the workspace behind the per-stage scratch, backward layout into the caller's saved
+    // packed_bwd buffers) in one launch; a stage without a packed_bwd buffer packs by itself as before
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    size_t stage_ws = 0;
+    for (int s = 0; s < stages; ++s) stage_ws = smax(stage_ws, hyb_convstage_fwd_workspace(dtype, s == 0, s == 0 ? 0 : padc(channels[s]), padc(channels[s + 1])));
+    stage_ws = al256(stage_ws);
+    const void* prepacked[17] = {nullptr};
+    {
+        const float* pw[16]; void* p0[16]; void* p1[16]; int co[16], ci[16], cop[16], cip[16];
+        char* q = (char*)workspace + stage_ws;
+        int n = 0;
+        for (int s = 1; s < stages; ++s) {
+            void* bwdpack = outs[(size_t)s * 6 + 4];
+            void* fwdpack = q;
+            q += al256((size_t)hyb_conv_packed_elems(0, padc(channels[s]), padc(channels[s + 1])) * es);
+            if (!bwdpack) continue;
+            pw[n] = params[(size_t)s * 5]; p0[n] = fwdpack; p1[n] = bwdpack;
+            co[n] = channels[s + 1]; ci[n] = channels[s]; cop[n] = padc(channels[s + 1]); cip[n] = padc(channels[s]);
+            prepacked[s] = fwdpack;
+            ++n;
+        }
+        if (n > 0) HYB_TRY(hyb_conv_pack_weight_many(dtype, n, pw, p0, p1, co, ci, cop, cip, (hipStream_t)stream));
+    }
     for (int s = 0; s < stages; ++s) {
         HYB_CHECK_ARG(h >= 2 && w >= 2);
         const float* const* P = params + (size_t)s * 5;
         void* const* O = outs + (size_t)s * 6;
         const int Ci = channels[s], Co = channels[s + 1];
-        // the workspace is reused by every stage: the stages are ordered on the stream
-        HYB_TRY(hyb_convstage_fwd(dtype, s == 0, in, P[0], P[1], P[2], (float*)P[3], (float*)P[4], nullptr, training, momentum, eps, N, h, w, Ci,
-                                  s == 0 ? 0 : padc(Ci), Co, padc(Co), O[0], O[1], (float*)O[2], (float*)O[3], O[4], training ? (float*)O[5] : nullptr,
-                                  workspace, workspace_bytes, stream));
+        // the per-stage scratch is reused by every stage: the stages are ordered on the stream
+        HYB_TRY(hyb_convstage_fwd_impl(dtype, s == 0, in, P[0], P[1], P[2], (float*)P[3], (float*)P[4], nullptr, training, momentum, eps, N, h, w, Ci,
+                                       s == 0 ? 0 : padc(Ci), Co, padc(Co), O[0], O[1], (float*)O[2], (float*)O[3], O[4], training ? (float*)O[5] : nullptr,
+                                       workspace, stage_ws, stream, prepacked[s]));
         in = O[1];
         h /= 2; w /= 2;
     }

@@ -107,10 +107,12 @@ extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int
     return align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es) + align256(2 * (size_t)Cop * 4) + align256(hyb_conv_stats_workspace(Cop));
 }
 
-extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
-                                 float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
-                                 int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
-                                 float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream) {
+// prepacked_fwd != NULL: the caller (hyb_backbone_fwd) has packed this stage's forward AND backward weights already
+int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
+                           int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
+                           float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream,
+                           const void* prepacked_fwd) {
     HYB_CHECK_ARG(x && weight && gamma && beta && running_mean && running_var && (first || y_raw) && pooled && scale_shift && mean_invstd && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(H >= 2 && W >= 2 && Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0);
@@ -123,7 +125,8 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
     void* wp = ws;
     float* stats = (float*)(ws + align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es));
     float* part = (float*)((char*)stats + align256(2 * (size_t)Cop * 4));
-    if (packed_bwd) HYB_TRY(hyb_conv_pack_weight_dual(dtype, weight, wp, packed_bwd, Co, Ci, Cop, Cip, (hipStream_t)stream));
+    if (prepacked_fwd) wp = const_cast<void*>(prepacked_fwd);
+    else if (packed_bwd) HYB_TRY(hyb_conv_pack_weight_dual(dtype, weight, wp, packed_bwd, Co, Ci, Cop, Cip, (hipStream_t)stream));
     else HYB_TRY(hyb_conv_pack_weight(dtype, 0, weight, wp, Co, Ci, Cop, Cip, stream));
     if (training) {   // conv leaves per-workgroup partial sums; one launch sums them in a fixed order and finalises BN
         HYB_TRY(hyb_conv3x3_fwd(dtype, 0, x, wp, y_raw, nullptr, part, N, H, W, Ci, Cip, Cop, stream));
@@ -136,6 +139,14 @@ extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const floa
     }
     HYB_TRY(hyb_bn_relu_pool_fwd(dtype, y_raw, scale_shift, pooled, N, H, W, Cop, stream));
     return 0;
+}
+
+extern "C" int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
+                                 int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
+                                 float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return hyb_convstage_fwd_impl(dtype, first, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Cip, Co,
+                                  Cop, y_raw, pooled, scale_shift, mean_invstd, packed_bwd, running_out, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop) {
