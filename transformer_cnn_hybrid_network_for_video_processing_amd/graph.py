@@ -2,7 +2,7 @@
 
 Why: the step is ~90 small-to-medium kernel launches; issued eagerly they cost the host 1.4 ms of Python + launch time for ~1.6 ms
 of GPU work (scripts/host_jitter.py), so any kernel speed-up beyond ~15 % -- and any slower host, e.g. 8 ranks sharing one
-machine -- would leave the GPU waiting.  Captured once (torch.cuda.graphs = HIP stream capture) the step is three graph launches.
+machine -- would leave the GPU waiting.  Captured once (torch.cuda.graphs = HIP stream capture) the step is one graph launch (three with data parallelism).
 
 The reference has nothing comparable (single process, eager); this is host-side scheduling only: the
 kernels, their order and their arithmetic are exactly those of the eager step, so results are bit-identical to eager for the
@@ -27,7 +27,8 @@ while the CNN backbone's backward graph executes:
     graph C: AdamW over all parameters (gradients = views of the buckets), step counter += 1
 
 With one rank there is nothing to exchange and no bucket: the gradient tensors produced under capture live at fixed addresses in
-the graphs' private pool, so they are bound to ``p.grad`` once and AdamW reads them in place (saves the two pack copies, ~25 us).
+the graphs' private pool, so they are bound to ``p.grad`` and AdamW reads them in place (saves the two pack copies, ~25 us); and the
+whole step is one graph (A, B and C captured back to back: every graph launch leaves the GPU idle for ~8 us, scripts/step_trace.py).
 """
 import torch
 import torch.distributed as dist
@@ -48,6 +49,7 @@ class GraphedTrainStep:
         self.x, self.y = x.clone(), y.clone()                 # static inputs: copy new batches in with load()
         self.mask = mask.clone() if mask is not None else None
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._one = None
         self.t_params = [p for p in model.temporal_parameters() if p.requires_grad]
         self.b_params = [p for p in model.backbone_parameters() if p.requires_grad]
         if len(self.t_params) + len(self.b_params) != sum(1 for p in model.parameters() if p.requires_grad):
@@ -80,9 +82,28 @@ class GraphedTrainStep:
             self._piece_a()
         with torch.cuda.graph(self.gb, pool=self.ga.pool()):
             self._piece_b()
-        with torch.cuda.graph(self.gc_, pool=self.ga.pool()):
-            self._piece_c()
+        self.gs = None
+        params = self.t_params + self.b_params
+        if self.world == 1:
+            # one rank: nothing happens between the pieces, so the whole step is ALSO captured as one graph (every graph launch leaves the
+            # GPU idle for ~8 us: two launches fewer per step).  Graphs A + B stay for fwd_bwd(); the two captures have their own gradient
+            # tensors, and p.grad is re-bound to the set the last call wrote.
+            self._grads_fb, self._loss_fb = [p.grad for p in params], self.loss
+            self.gs = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gs, pool=self.ga.pool()):
+                self._piece_a(); self._piece_b(); self._piece_c()
+            self._grads_step, self._loss_step = [p.grad for p in params], self.loss
+            self._bound = "step"
+        else:
+            with torch.cuda.graph(self.gc_, pool=self.ga.pool()):
+                self._piece_c()
         # the captures above did not execute: the state is still "after the warm-up steps"
+
+    def _bind(self, which):
+        if self.gs is not None and self._bound != which:
+            for p, g in zip(self.t_params + self.b_params, self._grads_step if which == "step" else self._grads_fb):
+                p.grad = g
+            self._bound = which
 
     @staticmethod
     def _bucket(params):
@@ -99,7 +120,9 @@ class GraphedTrainStep:
         h, B = self.model.forward_backbone(self.x)
         logits = self.model.forward_temporal(h, B, self.mask)
         loss = self.criterion(logits, self.y)
-        grads = torch.autograd.grad(loss, [h] + self.t_params)
+        if self._one is None:                                  # d(loss)/d(loss): a constant, not a fill launch per step
+            self._one = torch.ones_like(loss)
+        grads = torch.autograd.grad(loss, [h] + self.t_params, grad_outputs=self._one)
         self._h, self._gh = h, grads[0]
         self._deliver(self.t_params, self.t_views, grads[1:], bind)
         self.loss = loss.detach()
@@ -143,6 +166,11 @@ class GraphedTrainStep:
 
     def step(self):
         """One training step; returns the (device) loss tensor of this step -- reading it synchronises."""
+        if self.gs is not None:
+            self._bind("step")
+            self.gs.replay()
+            self.loss = self._loss_step
+            return self.loss
         self.ga.replay()
         w1 = self._reduce(self.t_bucket)                       # rides under graph B
         self.gb.replay()
@@ -154,12 +182,15 @@ class GraphedTrainStep:
 
     def fwd_bwd(self):
         """Forward + loss + backward (+ all-reduce) only: no optimizer, the step counter does not advance."""
+        self._bind("fb")
         self.ga.replay()
         w1 = self._reduce(self.t_bucket)
         self.gb.replay()
         w2 = self._reduce(self.b_bucket)
         self._reduce_wait(w1)
         self._reduce_wait(w2)
+        if self.gs is not None:
+            self.loss = self._loss_fb
         return self.loss
 
     def eager_fwd_bwd(self):
