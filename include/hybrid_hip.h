@@ -269,16 +269,19 @@ int hyb_cross_entropy_bwd(const float* logits, const long long* target, const fl
  *
  * hyb_backbone_*: `stages` conv stages, UNet.py:58-60 + UNet.py:13 each, in the order UNet.forward chains them (UNet.py:32-37).
  *   channels [stages+1] = {C_in (<= 4: the clip frames are read as NCHW fp32), C_1, ..., C_stages}.
- *   fwd params: HOST array of stages*5 device pointers {weight, gamma, beta, running_mean, running_var} (all read-only);
+ *   fwd params: HOST array of stages*5 device pointers {weight, gamma, beta, running_mean, running_var};
  *   fwd outs:   HOST array of stages*6 device pointers {y_raw (unused for stage 0), pooled, scale_shift, mean_invstd, packed_bwd,
- *               running_out [2][C_s] (training only; functional BatchNorm, see hyb_bn_finalize)}; pooled of stage s is the input
- *               of stage s+1, sizes as in hyb_convstage_fwd.
+ *               running_out}; pooled of stage s is the input of stage s+1, sizes as in hyb_convstage_fwd.
+ *   BatchNorm running statistics in training mode, per stage: running_out [2][C_s] != NULL -> functional (the updated statistics are
+ *               written there, running_mean / running_var are only read; see hyb_bn_finalize); running_out == NULL -> nn.BatchNorm2d's
+ *               own behaviour: running_mean / running_var are updated in place and *num_batches_tracked[s] += 1 (HOST array of
+ *               `stages` device pointers to 64-bit counters; the array or single entries may be NULL).
  *   bwd params: stages*2 {weight, gamma}; saved: stages*5 {y_raw, stage input (ignored for stage 0: x is passed), scale_shift,
  *               mean_invstd, packed_bwd}; grads: stages*3 {dweight, dgamma, dbeta}.  The clip tensor gets no gradient. */
 size_t hyb_backbone_fwd_workspace(int dtype, int stages, const int* channels);
-int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params, int training,
-                     float momentum, float eps, int N, int H, int W, void* const* outs, void* workspace, size_t workspace_bytes,
-                     void* stream);
+int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params,
+                     long long* const* num_batches_tracked, int training, float momentum, float eps, int N, int H, int W,
+                     void* const* outs, void* workspace, size_t workspace_bytes, void* stream);
 size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* channels, int N, int H, int W);
 int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last,
                      const void* pooled_last /* NULL, or the last stage's forward output */, const float* x, const float* const* params,
@@ -411,10 +414,12 @@ int hyb_dropout2d(const float* x, float* y, int N, long long HW, int C, float p,
  * elements); state tensors are caller-owned and must be zero before step 1.  Hyper-parameters are doubles (Python floats):
  * 1 - beta etc. are formed in double and rounded to fp32 once, like torch does.
  * step_inc: NULL, or a DEVICE pointer to one 64-bit counter: the step number used is step + *step_inc, read when the kernel runs
- * (the bias corrections are then formed on the device, in double) -- lets one captured launch serve every replay of a hipGraph. */
+ * (the bias corrections are then formed on the device, in double) -- lets one captured launch serve every replay of a hipGraph.
+ * advance != 0 (needs step_inc): the call also adds 1 to *step_inc once every workgroup has read it (the last workgroup to finish does
+ * it), so the replayed step needs no separate "counter += 1" launch; one advancing call at a time per device. */
 int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                    const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
-                   const long long* step_inc, void* stream);
+                   long long* step_inc, int advance, void* stream);
 
 #ifdef __cplusplus
 }

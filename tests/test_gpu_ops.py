@@ -129,7 +129,14 @@ def test_modules_dispatch_through_the_operators():
         loss = P().HybridCrossEntropyLoss()(m(x), y)
         loss.backward()
     hyb = [s.split(".")[1] for s in seen if s.startswith("hybrid.")]
-    assert hyb == ["backbone", "temporal", "cross_entropy", "cross_entropy_bwd", "temporal_bwd", "backbone_bwd"], hyb     # three calls each way
+    # three calls each way (training mode: the backbone operator that updates the BatchNorm buffers in place)
+    assert hyb == ["backbone_", "temporal", "cross_entropy", "cross_entropy_bwd", "temporal_bwd", "backbone_bwd"], hyb
+    m.eval()
+    seen.clear()
+    with Spy(), torch.no_grad():
+        m(x)
+    assert [s.split(".")[1] for s in seen if s.startswith("hybrid.")] == ["backbone", "temporal"]
+    m.train()
     seen.clear()
     m.fuse_model_ops = False                                       # one operator per stage (what standalone modules use)
     with Spy():
@@ -187,8 +194,23 @@ def test_opcheck_model_level_operators(dt):
     rvs = [torch.ones(c, device="cuda") for c in chans[1:]]
     for training in (True, False):
         _opcheck(torch.ops.hybrid.backbone.default, (x, ws, gs, bs, rms, rvs, training, 0.1, 1e-5, dt))
+    # the in-place form (nn.BatchNorm2d's buffer semantics): mutable schema, same outputs, buffers = the functional operator's running_out
+    nbts = [torch.full((), 5, dtype=torch.int64, device="cuda") for _ in chans[1:]]
+    assert "(a!)" in str(torch.ops.hybrid.backbone_.default._schema)
+    # (schema, autograd registration and fake kernel; torch's AOT functionalisation does not take custom operators that mix mutable tensor
+    # lists with a tensor-list result -- the functional hybrid::backbone above is the form to trace)
+    for training in (True, False):
+        torch.library.opcheck(torch.ops.hybrid.backbone_.default,
+                              (x, ws, gs, bs, [t.clone() for t in rms], [t.clone() for t in rvs], [t.clone() for t in nbts], training, 0.1, 1e-5, dt),
+                              test_utils=("test_schema", "test_autograd_registration", "test_faketensor"))
     res = torch.ops.hybrid.backbone(x, ws, gs, bs, rms, rvs, True, 0.1, 1e-5, dt)
     st = o._backbone_unpack(res, 2)
+    rm2, rv2 = [t.clone() for t in rms], [t.clone() for t in rvs]
+    res2 = torch.ops.hybrid.backbone_(x, ws, gs, bs, rm2, rv2, nbts, True, 0.1, 1e-5, dt)
+    assert torch.equal(res2[0], res[0])
+    for s_ in range(2):
+        assert torch.equal(rm2[s_], st[s_][5][0]) and torch.equal(rv2[s_], st[s_][5][1]) and int(nbts[s_].item()) == 6
+        assert torch.equal(rms[s_], torch.zeros_like(rms[s_]))                # the functional operator left its inputs alone
     saved = []
     for s in range(2):
         saved += [st[s][0].detach(), (st[s - 1][1] if s > 0 else st[s][0]).detach(), st[s][2].detach(), st[s][3].detach(), st[s][4].detach()]

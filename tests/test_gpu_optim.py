@@ -87,3 +87,30 @@ def test_adamw_reload_into_the_same_optimizer_midrun():
         torch.testing.assert_close(pb.data, pa.data, rtol=2e-6, atol=2e-7)
         torch.testing.assert_close(ob.state[pb]["exp_avg"], oa.state[pa]["exp_avg"], rtol=2e-6, atol=1e-12)
         assert int(ob.state[pb]["step"]) == 2
+
+
+def test_adamw_device_step_counter_advanced_by_the_launch_itself():
+    """hyb_adamw_step(advance=1): the step number is state['step'] + *counter, and the launch adds 1 to the counter after every workgroup
+    has read it -- same parameters, bit for bit, as the host-stepped optimizer, and the counter counts the steps."""
+    init = _params(3)
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    b = [torch.nn.Parameter(t.clone()) for t in init]
+    oa = P.HybridAdamW(a, lr=1e-3)
+    ob = P.HybridAdamW(b, lr=1e-3)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ob.set_step_counter(counter, advance=True)
+    g = torch.Generator().manual_seed(4)
+    for step in range(6):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad = gr.clone(); pb.grad = gr.clone()
+        oa.step(); ob.step()
+        assert int(counter.item()) == step + 1
+        for pa, pb in zip(a, b):
+            # the device forms the bias corrections with its own pow(): equal to the host's to the last bit or one ulp of the step size
+            torch.testing.assert_close(pb.data, pa.data, rtol=1e-6, atol=1e-7)
+    ob.set_step_counter(None)
+    two = P.HybridAdamW([{"params": b[:2]}, {"params": b[2:]}], lr=1e-3)
+    two.set_step_counter(counter, advance=True)
+    with pytest.raises(RuntimeError, match="one parameter group"):
+        two.step()

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built):
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in built.protos:
         assert hasattr(dll, name), f"{name} declared in include/hybrid_hip.h but not exported"
-    assert built.query("hyb_abi_version") == 6
+    assert built.query("hyb_abi_version") == 7
     assert built.query("hyb_dtype_size", 0) == 4 and built.query("hyb_dtype_size", 1) == 2 and built.query("hyb_dtype_size", 7) == -1
     assert built.query("hyb_pad_channels", 3) == 32 and built.query("hyb_pad_channels", 64) == 64 and built.query("hyb_pad_channels", 65) == 96
 
@@ -56,7 +56,7 @@ def test_argument_checks_fail_without_a_device(built):
     assert built.raw("hyb_linear_fwd")(1, None, 8, None, None, None, 4, 8, 8, 0, None) == -1
     assert built.raw("hyb_attention_fwd")(1, None, None, None, None, None, None, 1, 4, 8, 2, 0.0, 0, None) == -1
     assert built.raw("hyb_cross_entropy_fwd")(None, None, None, 1, 2, None) == -1
-    assert built.raw("hyb_adamw_step")(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None, None) == -1
+    assert built.raw("hyb_adamw_step")(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None, 0, None) == -1
     with pytest.raises(RuntimeError, match="argument check"):
         built.call("hyb_gap_fwd", 1, None, None, 1, 1, 32, None)
     # workspace / size queries are pure host functions

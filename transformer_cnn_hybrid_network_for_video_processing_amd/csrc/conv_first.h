@@ -27,6 +27,18 @@ struct S1Args {
     int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
 };
 
+// One element of the packed first-layer weights [2][Cop][64] (shared by s1w_pack_kernel and the backbone's one pack launch, conv_fwd.hip):
+// half 0 in the block-level kernels' K order (k = tap*4 + c), half 1 in the wave-private kernels' order (k = slot*4 + c, slot -> tap below;
+// slot pairs (2q, 2q+1) of a k-step are horizontally adjacent pixels; -1 = zero weights).  i indexes one half: co = i / 64, k = i % 64.
+__device__ __forceinline__ float s1w_pack_value(const float* __restrict__ w, long long i, bool second, int Co, int Ci) {
+    const int k = (int)(i % 64), co = (int)(i / 64);
+    const int slot = k >> 2, c = k & 3;
+    //                  k-step 0: (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (0,2)  -    k-step 1: (1,2) -  (2,2) -   -   -   -   -
+    const int tap_of_slot[16] = {0, 1, 3, 4, 6, 7, 2, -1, 5, -1, 8, -1, -1, -1, -1, -1};
+    const int tap = second ? tap_of_slot[slot] : (slot < 9 ? slot : -1);
+    return (co < Co && tap >= 0 && c < Ci) ? w[((long long)co * Ci + c) * 9 + tap] : 0.f;
+}
+
 // conv_first_wave.hip
 int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, int Cop, int both, hipStream_t st);
 int hyb_stage1w_bwd(int dtype, S1Args a, int with_g /* 0: rows are Cop x 48 (G saved by the forward pass) */, int& grid_x /* in: wanted workgroups; out: launched = partial rows */, hipStream_t st);

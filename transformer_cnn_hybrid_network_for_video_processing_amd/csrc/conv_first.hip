@@ -557,7 +557,7 @@ template <typename T>
 static int stage1_fwd_t(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co,
                         int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out,
-                        hipStream_t st) {
+                        int prepacked, hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     // packed weights in both K orders; kept for backward when asked (packed_out = [2][Cop][64])
@@ -583,7 +583,9 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     const bool use_gram = gram_env && wave_private && training && sizeof(T) == 2 && (W % 16 == 0) && (H % 8 == 0);
     const bool need_a = packed_out || !wave_private || use_gram;     // k = tap*4 + c: the block-level kernels, the Gram statistics, the backward pass
     const bool need_b = wave_private || packed_out;
-    if (need_a && need_b && wp2 == wp + (size_t)Cop * 64) {          // the two layouts are adjacent (always: Cop*64*es is a multiple of 256): one launch
+    if (prepacked && packed_out) {
+        // the caller (hyb_backbone_fwd) has written both layouts into packed_out already, in its one pack launch
+    } else if (need_a && need_b && wp2 == wp + (size_t)Cop * 64) {          // the two layouts are adjacent (always: Cop*64*es is a multiple of 256): one launch
         if (int e = hyb_stage1w_pack(dtype, weight, wp, Co, Ci, Cop, 1, st)) return e;
     } else {
         if (need_a) {
@@ -697,10 +699,11 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
 
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, hipStream_t st) {
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, int prepacked,
+                   hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, st);
-    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, st);
+    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, st);
+    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, st);
     return HYB_E_ARG;
 }
 

@@ -674,13 +674,7 @@ __global__ void s1w_pack_kernel(const float* __restrict__ w, T* __restrict__ wp2
     const bool second = !both || i >= total;
     T* dst = wp2 + i;
     if (both && second) i -= total;
-    const int k = (int)(i % 64), co = (int)(i / 64);
-    const int slot = k >> 2, c = k & 3;
-    //                  k-step 0: (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (0,2)  -    k-step 1: (1,2) -  (2,2) -   -   -   -   -
-    const int tap_of_slot[16] = {0, 1, 3, 4, 6, 7, 2, -1, 5, -1, 8, -1, -1, -1, -1, -1};
-    const int tap = second ? tap_of_slot[slot] : (slot < 9 ? slot : -1);
-    float v = 0.f;
-    if (co < Co && tap >= 0 && c < Ci) v = w[((long long)co * Ci + c) * 9 + tap];
+    const float v = s1w_pack_value(w, i, second, Co, Ci);
     *dst = from_f32<T>(v);
 }
 

@@ -11,6 +11,7 @@
 // output channel, UNet.py:59) into the epilogue from the fp32 accumulators.
 #include <stdlib.h>
 #include "hyb_common.h"
+#include "conv_first.h"
 
 namespace {
 
@@ -610,12 +611,23 @@ int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, i
 
 // The same for SEVERAL stages in one launch (internal; hyb_backbone_fwd): blockIdx.y = stage.  The weights do not depend on the
 // activations, so the whole backbone's packs can run before its first convolution (three 5 us launches fewer per step at config 2).
-struct PackMany { const float* w[16]; void* wp0[16]; void* wp1[16]; int Co[16], Ci[16], Cop[16], Cip[16]; };
+struct PackMany {
+    const float* w[16]; void* wp0[16]; void* wp1[16]; int Co[16], Ci[16], Cop[16], Cip[16];
+    // + the first stage's [2][Cop][64] pack (conv_first.h) as row blockIdx.y = n when s1_wp != NULL
+    const float* s1_w; void* s1_wp; int s1_Co, s1_Ci, s1_Cop; int n;
+};
 template <typename T>
 __global__ void pack_weight_many_kernel(PackMany a) {
     const int s = blockIdx.y;
-    const long long count = (long long)a.Cop[s] * 9 * a.Cip[s];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == a.n) {                                       // first stage (uniform per workgroup)
+        const long long total = (long long)a.s1_Cop * 64;
+        if (i >= 2 * total) return;
+        const bool second = i >= total;
+        ((T*)a.s1_wp)[i] = from_f32<T>(s1w_pack_value(a.s1_w, second ? i - total : i, second, a.s1_Co, a.s1_Ci));
+        return;
+    }
+    const long long count = (long long)a.Cop[s] * 9 * a.Cip[s];
     if (i >= 2 * count) return;
     const float* __restrict__ w = a.w[s];
     const int Co = a.Co[s], Ci = a.Ci[s], Cop = a.Cop[s], Cip = a.Cip[s];
@@ -638,9 +650,10 @@ __global__ void pack_weight_many_kernel(PackMany a) {
         ((T*)a.wp1[s])[k] = from_f32<T>(v);
     }
 }
+// s1_wp != NULL: also the first stage's two layouts (s1_w [s1_Co][s1_Ci][3][3] -> s1_wp [2][s1_Cop][64])
 int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* const* wp0, void* const* wp1, const int* Co, const int* Ci, const int* Cop,
-                              const int* Cip, hipStream_t st) {
-    if (n < 1 || n > 16) return HYB_E_ARG;
+                              const int* Cip, const float* s1_w, void* s1_wp, int s1_Co, int s1_Ci, int s1_Cop, hipStream_t st) {
+    if (n < 0 || n > 16 || (n == 0 && !s1_wp)) return HYB_E_ARG;
     PackMany a{};
     long long maxc = 0;
     for (int i = 0; i < n; ++i) {
@@ -648,7 +661,9 @@ int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* con
         const long long c = (long long)Cop[i] * 9 * Cip[i];
         if (c > maxc) maxc = c;
     }
-    const dim3 grid(hyb_cdiv(2 * maxc, 256), n);
+    a.n = n; a.s1_w = s1_w; a.s1_wp = s1_wp; a.s1_Co = s1_Co; a.s1_Ci = s1_Ci; a.s1_Cop = s1_Cop;
+    if (s1_wp && (long long)s1_Cop * 64 > maxc) maxc = (long long)s1_Cop * 64;
+    const dim3 grid(hyb_cdiv(2 * maxc, 256), n + (s1_wp ? 1 : 0));
     if (dtype == HYB_F32) hipLaunchKernelGGL(pack_weight_many_kernel<float>, grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(pack_weight_many_kernel<bf16>, grid, dim3(256), 0, st, a);
     else return HYB_E_ARG;

@@ -13,7 +13,7 @@ int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* wei
                            float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream,
                            const void* prepacked_fwd);
 int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* const* wp0, void* const* wp1, const int* Co, const int* Ci, const int* Cop,
-                              const int* Cip, hipStream_t st);
+                              const int* Cip, const float* s1_w, void* s1_wp, int s1_Co, int s1_Ci, int s1_Cop, hipStream_t st);
 
 namespace {
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -33,9 +33,9 @@ extern "C" size_t hyb_backbone_fwd_workspace(int dtype, int stages, const int* c
     return al256(b) + packs;
 }
 
-extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params, int training,
-                                float momentum, float eps, int N, int H, int W, void* const* outs, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, const float* x, const float* const* params,
+                                long long* const* num_batches_tracked, int training, float momentum, float eps, int N, int H, int W,
+                                void* const* outs, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG(stages >= 1 && stages <= 16 && channels && x && params && outs && workspace && N > 0);
     HYB_CHECK_ARG(channels[0] >= 1 && channels[0] <= 4);                  // the first stage reads NCHW fp32 frames directly
     if (workspace_bytes < hyb_backbone_fwd_workspace(dtype, stages, channels)) return HYB_E_WORKSPACE;
@@ -62,7 +62,12 @@ extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, cons
             prepacked[s] = fwdpack;
             ++n;
         }
-        if (n > 0) HYB_TRY(hyb_conv_pack_weight_many(dtype, n, pw, p0, p1, co, ci, cop, cip, (hipStream_t)stream));
+        // the first stage's two layouts ([2][Cop][64] at the head of its packed_bwd buffer) ride in the same launch
+        void* s1pack = outs[4];
+        if (s1pack) prepacked[0] = s1pack;
+        if (n > 0 || s1pack)
+            HYB_TRY(hyb_conv_pack_weight_many(dtype, n, pw, p0, p1, co, ci, cop, cip, params[0], s1pack, channels[1], channels[0], padc(channels[1]),
+                                              (hipStream_t)stream));
     }
     for (int s = 0; s < stages; ++s) {
         HYB_CHECK_ARG(h >= 2 && w >= 2);
@@ -70,7 +75,10 @@ extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, cons
         void* const* O = outs + (size_t)s * 6;
         const int Ci = channels[s], Co = channels[s + 1];
         // the per-stage scratch is reused by every stage: the stages are ordered on the stream
-        HYB_TRY(hyb_convstage_fwd_impl(dtype, s == 0, in, P[0], P[1], P[2], (float*)P[3], (float*)P[4], nullptr, training, momentum, eps, N, h, w, Ci,
+        // training: running_out (O[5]) != NULL -> functional BatchNorm (the updated statistics go there, the inputs stay untouched);
+        // NULL -> nn.BatchNorm2d's own in-place update of running_mean / running_var and num_batches_tracked += 1
+        HYB_TRY(hyb_convstage_fwd_impl(dtype, s == 0, in, P[0], P[1], P[2], (float*)P[3], (float*)P[4],
+                                       num_batches_tracked ? num_batches_tracked[s] : nullptr, training, momentum, eps, N, h, w, Ci,
                                        s == 0 ? 0 : padc(Ci), Co, padc(Co), O[0], O[1], (float*)O[2], (float*)O[3], O[4], training ? (float*)O[5] : nullptr,
                                        workspace, stage_ws, stream, prepacked[s]));
         in = O[1];

@@ -35,7 +35,8 @@ size_t hyb_stage1_fwd_workspace(int dtype, int Cop);
 size_t hyb_stage1_bwd_workspace(int dtype, int Cop);
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
-                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, hipStream_t st);
+                   void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, int prepacked,
+                   hipStream_t st);
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
                    float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
@@ -107,7 +108,8 @@ extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int
     return align256((size_t)hyb_conv_packed_elems(first, Cip, Cop) * es) + align256(2 * (size_t)Cop * 4) + align256(hyb_conv_stats_workspace(Cop));
 }
 
-// prepacked_fwd != NULL: the caller (hyb_backbone_fwd) has packed this stage's forward AND backward weights already
+// prepacked_fwd != NULL: the caller (hyb_backbone_fwd) has packed this stage's forward AND backward weights already (first stage: both
+// layouts in packed_bwd; the pointer is only a flag there)
 int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                            int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
@@ -119,7 +121,8 @@ int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* wei
     if (workspace_bytes < hyb_convstage_fwd_workspace(dtype, first, Cip, Cop)) return HYB_E_WORKSPACE;
     if (first)      // stage 1: the raw conv output is never materialised (recomputed in backward), y_raw is ignored
         return hyb_stage1_fwd(dtype, (const float*)x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci,
-                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, running_out, (hipStream_t)stream);
+                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, running_out, prepacked_fwd != nullptr,
+                              (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     void* wp = ws;

@@ -30,6 +30,8 @@ With one rank there is nothing to exchange and no bucket: the gradient tensors p
 the graphs' private pool, so they are bound to ``p.grad`` and AdamW reads them in place (saves the two pack copies, ~25 us); and the
 whole step is one graph (A, B and C captured back to back: every graph launch leaves the GPU idle for ~8 us, scripts/step_trace.py).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -63,7 +65,9 @@ class GraphedTrainStep:
                     dist.broadcast(t.data, src=0, group=process_group)
 
         ops.set_step_counter(self.counter)
-        optimizer.set_step_counter(self.counter)
+        # one parameter group: the AdamW launch itself advances the counter (no separate `counter += 1` launch per step)
+        self._advancing = sum(1 for g in optimizer.param_groups if any(p.requires_grad for p in g["params"])) == 1
+        optimizer.set_step_counter(self.counter, advance=self._advancing)
         if self.world > 1:
             for p, v in zip(self.t_params + self.b_params, self.t_views + self.b_views):
                 p.grad = v                                     # AdamW reads the (all-reduced) buckets in place
@@ -84,7 +88,7 @@ class GraphedTrainStep:
             self._piece_b()
         self.gs = None
         params = self.t_params + self.b_params
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("HYB_GRAPH_SINGLE", "1") != "0":      # (=0: A/B switch, the three-graph form)
             # one rank: nothing happens between the pieces, so the whole step is ALSO captured as one graph (every graph launch leaves the
             # GPU idle for ~8 us: two launches fewer per step).  Graphs A + B stay for fwd_bwd(); the two captures have their own gradient
             # tensors, and p.grad is re-bound to the set the last call wrote.
@@ -144,7 +148,8 @@ class GraphedTrainStep:
             self.t_bucket.mul_(1.0 / self.world)
             self.b_bucket.mul_(1.0 / self.world)
         self.optimizer.step()
-        self.counter.add_(1)
+        if not self._advancing:
+            self.counter.add_(1)
 
     def _reduce(self, bucket):
         if self.world == 1:

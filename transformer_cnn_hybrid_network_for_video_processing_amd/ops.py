@@ -646,7 +646,27 @@ def backbone_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], 
     """All conv stages of the backbone on NCHW fp32 frames x [N, C_in <= 4, H, W].
     -> [pooled_S, then per stage s: y_raw_s, pooled_s (s < S-1 only), scale_shift_s, mean_invstd_s, packed_bwd_s, running_out_s]
     (functional BatchNorm: running_out_s [2, C_s] holds the updated statistics in training mode, empty otherwise)."""
+    return _backbone_impl(x, weights, gammas, betas, running_means, running_vars, None, training, momentum, eps, dt)
+
+
+def backbone_inplace_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], betas: Sequence[Tensor], running_means: Sequence[Tensor],
+                        running_vars: Sequence[Tensor], num_batches_tracked: Sequence[Tensor], training: bool, momentum: float, eps: float,
+                        dt: int) -> List[Tensor]:
+    """hybrid::backbone with nn.BatchNorm2d's own buffer semantics: in training mode running_means / running_vars are updated in place by
+    the statistics kernels and every num_batches_tracked advances by one (no write-back launches); same outputs, running_out_s empty."""
+    return _backbone_impl(x, weights, gammas, betas, running_means, running_vars, list(num_batches_tracked), training, momentum, eps, dt)
+
+
+def _backbone_impl(x, weights, gammas, betas, running_means, running_vars, nbts, training, momentum, eps, dt):
+    inplace = nbts is not None
     _require_cuda(x, *weights)
+    if inplace:
+        for t in list(running_means) + list(running_vars):
+            if not (t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError("hybrid::backbone_ updates contiguous fp32 running statistics in place")
+        for t in nbts:
+            if not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+                raise RuntimeError("hybrid::backbone_: num_batches_tracked must be cuda int64 scalars")
     x = x.contiguous()
     S = len(weights)
     N, H, W, chans, dims = _backbone_geometry(x, weights)
@@ -665,22 +685,27 @@ def backbone_op(x: Tensor, weights: Sequence[Tensor], gammas: Sequence[Tensor], 
         ss = torch.empty(2, Cop, dtype=torch.float32, device=dev)
         mi = torch.empty(2, Cop, dtype=torch.float32, device=dev)
         pk = torch.empty(_query("hyb_convstage_packed_bwd_elems", int(s == 0), Cip, Cop), dtype=tdt, device=dev)
-        ro = torch.empty((2, Co) if training else (0,), dtype=torch.float32, device=dev)
+        ro = torch.empty((2, Co) if training and not inplace else (0,), dtype=torch.float32, device=dev)
         per_stage.append((y_raw, pooled, ss, mi, pk, ro))
         params += [weights[s].contiguous().data_ptr(), gammas[s].contiguous().data_ptr(), betas[s].contiguous().data_ptr(),
                    running_means[s].contiguous().data_ptr(), running_vars[s].contiguous().data_ptr()]
-        outs += [None if s == 0 else y_raw.data_ptr(), pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(), pk.data_ptr(), ro.data_ptr() if training else None]
+        outs += [None if s == 0 else y_raw.data_ptr(), pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(), pk.data_ptr(),
+                 ro.data_ptr() if training and not inplace else None]
     ch = _int_array(chans)
     ws = _ws(_query("hyb_backbone_fwd_workspace", dt, S, tuple(chans)), dev)
-    lib.call("hyb_backbone_fwd", dt, S, ch, x.data_ptr(), ptr_array(params), int(training), float(momentum), float(eps), N, H, W,
-             ptr_array(outs), ws.data_ptr(), ws.numel(), _stream())
+    lib.call("hyb_backbone_fwd", dt, S, ch, x.data_ptr(), ptr_array(params), ptr_array([t.data_ptr() for t in nbts]) if inplace else None,
+             int(training), float(momentum), float(eps), N, H, W, ptr_array(outs), ws.data_ptr(), ws.numel(), _stream())
     res = [pooled]
     for s, (y_raw, p, ss, mi, pk, ro) in enumerate(per_stage):
         res += [y_raw] + ([p] if s < S - 1 else []) + [ss, mi, pk, ro]
     return res
 
 
-def backbone_fake(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt):
+def backbone_inplace_fake(x, weights, gammas, betas, running_means, running_vars, num_batches_tracked, training, momentum, eps, dt):
+    return backbone_fake(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt, functional=False)
+
+
+def backbone_fake(x, weights, gammas, betas, running_means, running_vars, training, momentum, eps, dt, functional=True):
     S = len(weights)
     N, H, W, chans, dims = _backbone_geometry(x, weights)
     tdt = _TORCH_DTYPE[dt]
@@ -691,7 +716,7 @@ def backbone_fake(x, weights, gammas, betas, running_means, running_vars, traini
         res += [x.new_empty((0,) if s == 0 else (N, h, w_, Cop), dtype=tdt)] + ([last] if s < S - 1 else []) + [
             x.new_empty((2, Cop), dtype=torch.float32), x.new_empty((2, Cop), dtype=torch.float32),
             x.new_empty((_query("hyb_convstage_packed_bwd_elems", int(s == 0), Cip, Cop),), dtype=tdt),
-            x.new_empty((2, chans[s + 1]) if training else (0,), dtype=torch.float32)]
+            x.new_empty((2, chans[s + 1]) if training and functional else (0,), dtype=torch.float32)]
     return [last] + res
 
 
@@ -749,6 +774,12 @@ def backbone_bwd_fake(dpooled, pooled, x, weights, gammas, saved, training, dt):
 def backbone(x, stages, training, dt):
     """stages: list of (conv.weight, bn) pairs.  Applies nn.BatchNorm2d's buffer updates after the functional operator."""
     bns = [bn for _, bn in stages]
+    if training and all(bn.num_batches_tracked is not None and bn.num_batches_tracked.is_cuda and bn.running_mean.is_contiguous()
+                        and bn.running_var.is_contiguous() for bn in bns):
+        # the statistics kernels update the modules' buffers themselves (nn.BatchNorm2d's in-place semantics): no write-back launches
+        return torch.ops.hybrid.backbone_(x, [w for w, _ in stages], [bn.weight for bn in bns], [bn.bias for bn in bns],
+                                          [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
+                                          [bn.num_batches_tracked for bn in bns], True, float(bns[0].momentum), float(bns[0].eps), int(dt))[0]
     res = torch.ops.hybrid.backbone(x, [w for w, _ in stages], [bn.weight for bn in bns], [bn.bias for bn in bns],
                                     [bn.running_mean for bn in bns], [bn.running_var for bn in bns], bool(training), float(bns[0].momentum),
                                     float(bns[0].eps), int(dt))
@@ -1004,8 +1035,13 @@ class _BackboneFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise RuntimeError(_CLIP_GRAD_MSG)
         weights, gammas, betas, rms, rvs = (tensors[i * S:(i + 1) * S] for i in range(5))
+        nbts = tensors[5 * S:]                             # hybrid::backbone_ only
+        ctx.n_extra = len(tensors) - 3 * S
         with _below_autograd():
-            res = torch.ops.hybrid.backbone(x, weights, gammas, betas, rms, rvs, training, momentum, eps, dt)
+            if nbts:                                       # (the buffers carry no gradient: nothing to tell autograd about their update)
+                res = torch.ops.hybrid.backbone_(x, weights, gammas, betas, rms, rvs, nbts, training, momentum, eps, dt)
+            else:
+                res = torch.ops.hybrid.backbone(x, weights, gammas, betas, rms, rvs, training, momentum, eps, dt)
         st = _backbone_unpack(res, S)
         saved = []
         for s in range(S):
@@ -1020,7 +1056,7 @@ class _BackboneFn(torch.autograd.Function):
         S, training, dt = ctx.cfg
         t = ctx.saved_tensors
         g = torch.ops.hybrid.backbone_bwd(dpooled, t[1], t[0], t[2:2 + S], t[2 + S:2 + 2 * S], t[2 + 2 * S:], training, dt)
-        return (None,) * 6 + tuple(g[0::3]) + tuple(g[1::3]) + tuple(g[2::3]) + (None,) * (2 * S)
+        return (None,) * 6 + tuple(g[0::3]) + tuple(g[1::3]) + tuple(g[2::3]) + (None,) * ctx.n_extra
 
 
 class _TemporalFn(torch.autograd.Function):
@@ -1078,6 +1114,10 @@ _define("backbone", "(Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] beta
         "float momentum, float eps, int dt) -> Tensor[]", backbone_op, backbone_fake,
         lambda x, ws, gs, bs, rms, rvs, training, momentum, eps, dt: list(_BackboneFn.apply(x, len(ws), training, momentum, eps, dt, *ws, *gs, *bs,
                                                                                           *rms, *rvs)))
+_define("backbone_", "(Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] betas, Tensor(a!)[] running_means, Tensor(b!)[] running_vars, "
+        "Tensor(c!)[] num_batches_tracked, bool training, float momentum, float eps, int dt) -> Tensor[]", backbone_inplace_op, backbone_inplace_fake,
+        lambda x, ws, gs, bs, rms, rvs, nbts, training, momentum, eps, dt: list(_BackboneFn.apply(x, len(ws), training, momentum, eps, dt, *ws, *gs,
+                                                                                                *bs, *rms, *rvs, *nbts)))
 _define("backbone_bwd", "(Tensor dpooled, Tensor pooled, Tensor x, Tensor[] weights, Tensor[] gammas, Tensor[] saved, bool training, int dt) -> Tensor[]",
         backbone_bwd_op, backbone_bwd_fake)
 _define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_params, Tensor head_w, Tensor head_b, Tensor? mask, int B, int dt, "

@@ -18,11 +18,15 @@ class HybridAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}            # per group: cached pointer tables of the tensors whose addresses never change
         self._step_counter = None    # device int64 [1]: the kernel uses step + counter (captured launches, graph.GraphedTrainStep)
+        self._advance = False
 
-    def set_step_counter(self, counter):
+    def set_step_counter(self, counter, advance=False):
         """With a device counter the step number used by the kernel is state['step'] + counter, read on the device: one captured
-        launch then serves every replay of a hipGraph (the counter is advanced inside the graph)."""
+        launch then serves every replay of a hipGraph.  advance=True: step() also adds 1 to the counter (inside the AdamW launch, after
+        every workgroup has read it) -- the caller then needs no separate `counter += 1` launch; every parameter must then be in
+        ONE group, so that one launch ends the step."""
         self._step_counter = counter
+        self._advance = bool(advance) and counter is not None
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -45,6 +49,9 @@ class HybridAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        live = [gi for gi, group in enumerate(self.param_groups) if any(p.grad is not None for p in group["params"])]
+        if self._advance and len(live) != 1:
+            raise RuntimeError("HybridAdamW: an advancing step counter needs exactly one parameter group with gradients")
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -80,5 +87,5 @@ class HybridAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             lib.call("hyb_adamw_step", len(ps), tab[2], ptr_array([g.data_ptr() for g in grads]), tab[3], tab[4], tab[5],
                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(),
-                     self._step_counter.data_ptr() if self._step_counter is not None else None, _stream())
+                     self._step_counter.data_ptr() if self._step_counter is not None else None, int(self._advance), _stream())
         return loss
