@@ -140,6 +140,37 @@ def test_conv_stage_matches_oracle(mode, ci, co, n, h, w, training):
         assert int(bn_h.num_batches_tracked) == int(bn_r.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("ci,co,n,h,w", [(3, 32, 2, 16, 32), (3, 64, 2, 8, 16), (3, 32, 3, 40, 64), (1, 32, 2, 16, 32), (4, 32, 1, 8, 16),
+                                         (3, 32, 2, 16, 20), (3, 8, 2, 16, 16), (32, 64, 2, 16, 16), (64, 128, 2, 28, 28), (128, 256, 1, 14, 14),
+                                         (64, 64, 2, 29, 57), (96, 96, 1, 8, 12)])
+@pytest.mark.parametrize("training", [True, False])
+def test_conv_stage_split_bf16_mode_matches_the_fp32_oracle(ci, co, n, h, w, training):
+    """compute_dtype="bf16x3" (libhybrid_hip_x3.so: fp32 storage, every product from three bf16 MFMAs on two-term splits) on one conv stage
+    against the fp32 oracle at the exact-fp32 mode's own gates (1e-4 forward, 1e-3 gradients): first-stage shapes that take the
+    wave-private kernels with their pre-split LDS planes (8x16 blocks, 1..4 input channels, 32 / 64 output channels), a ragged one that takes
+    the block-level kernel with element-packed LDS words, and later-stage shapes (pre-split halo images and packed weights in the
+    convolution, element-packed tiles in the weight gradient)."""
+    ftol, gtol = TOL["fp32"]
+    ref, hip = _stage_pair(ci, co, "enc1", "bf16x3")
+    ref.train(training); hip.train(training)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(n, ci, h, w, generator=g)
+    r = torch.randn(n, co, h // 2, w // 2, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * r).sum().backward()
+    xh = x.cuda().requires_grad_(ci > 4)
+    yh = hip(xh)
+    (yh * r.cuda()).sum().backward()
+    check(yh, yr, ftol, "pooled")
+    check_param_grads(hip, ref, gtol, "fp32")
+    if ci > 4:
+        check(xh.grad, xr.grad, gtol, "dx")
+    if training:
+        check(hip.enc1norm1.running_mean, ref.enc1norm1.running_mean, 1e-4, "running_mean")
+        check(hip.enc1norm1.running_var, ref.enc1norm1.running_var, 1e-4, "running_var")
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_conv_stage_with_zero_and_tiny_gammas(training):
     """The backward's per-channel sums are formed from the pooled output as (pooled - beta) / gamma; a channel whose gamma is exactly

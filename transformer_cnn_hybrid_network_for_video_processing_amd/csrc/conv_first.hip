@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
         const T* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
         frag_load(w0[t], row);
         frag_load(w1[t], row + 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w0[t].v[j] = hyb_epack(w0[t].v[j]); w1[t].v[j] = hyb_epack(w1[t].v[j]); }
     }
     float c_sc[NT][4], c_sh[NT][4];
     if (MODE >= 1) {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             for (int i = 0; i < 4; ++i) {
                 Quad<T> qv;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                for (int c = 0; c < 4; ++c) qv.v[c] = hyb_epack(from_f32<T>(pf[c][i]));      // (split-bf16 build: element-packed LDS, hyb_common.h)
                 *reinterpret_cast<Quad<T>*>(img + (tid * 4 + i) * 4) = qv;       // pixel (row, 4*seg + i) = tid*4 + i
             }
         }
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
             s1_bfrag(b1, img, base_el, q, 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[j][t] = mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
-                acc[j][t] = mma32(w1[t], b1, acc[j][t]);
+                acc[j][t] = mma32_e(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[j][t] = mma32_e(w1[t], b1, acc[j][t]);
             }
         }
         const int gy0 = ty0 + 2 * wy, gx0 = tx0 + wave * 8 + 2 * wx;          // window origin
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int pix = (2 * wy + (j >> 1)) * S1_TW + wave * 8 + 2 * wx + (j & 1);
+                    o[j].epack();
                     o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
                 }
             }
@@ -322,11 +325,11 @@ __global__ __launch_bounds__(256) void stage1_kernel(S1Args a) {
                 for (int kt = 0; kt < 3; ++kt) {
                     tr_frag_s1(bf[kt], P + (row * S1_TW + 4 * q) * S1_PS + kt * 16, S1_PS, 16, lane);
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32(af[c], bf[kt], wacc[kt][c]);
+                    for (int c = 0; c < NT; ++c) wacc[kt][c] = mma32_e(af[c], bf[kt], wacc[kt][c]);
                 }
                 if (MODE == 4 && blockIdx.y == 0) {       // Gram matrix of the patches: A and B fragments have the same lane layout
-                    gacc[0] = mma32(bf[0], bf[0], gacc[0]); gacc[1] = mma32(bf[0], bf[1], gacc[1]); gacc[2] = mma32(bf[0], bf[2], gacc[2]);
-                    gacc[3] = mma32(bf[1], bf[1], gacc[3]); gacc[4] = mma32(bf[1], bf[2], gacc[4]); gacc[5] = mma32(bf[2], bf[2], gacc[5]);
+                    gacc[0] = mma32_e(bf[0], bf[0], gacc[0]); gacc[1] = mma32_e(bf[0], bf[1], gacc[1]); gacc[2] = mma32_e(bf[0], bf[2], gacc[2]);
+                    gacc[3] = mma32_e(bf[1], bf[1], gacc[3]); gacc[4] = mma32_e(bf[1], bf[2], gacc[4]); gacc[5] = mma32_e(bf[2], bf[2], gacc[5]);
                 }
             }
         }
@@ -653,7 +656,9 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     float* part = (float*)ws;
     // the wave-private kernel: 16-bit storage, aligned float4 row segments, no ragged 8x16 blocks, 32-bit buffer offsets
     static const int wave_env = getenv("HYB_S1_WAVE_BWD") ? atoi(getenv("HYB_S1_WAVE_BWD")) : 1;
-    const bool wave_private = wave_env && sizeof(T) == 2 && (W % 16 == 0) && (H % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+    // (fp32 storage: only the split-bf16 build has a wave-private kernel, conv_first_wave.hip)
+    const bool wave_private = wave_env && (sizeof(T) == 2 || HYB_X3) && (W % 16 == 0) && (H % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                              (((uintptr_t)dpooled & 15) == 0) && (Cop % 4 == 0) &&
                               (long long)N * Ci * H * W * 4 < (1ll << 32) && (long long)N * (H / 2) * (W / 2) * Cop * (long long)es < (1ll << 32);
     const int dtype = sizeof(T) == 2 ? HYB_BF16 : HYB_F32;
     if (packed_in) {
@@ -684,7 +689,7 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     const long long roww = (long long)Cop * 48 + 2304;
     // the forward pass of a training step (same conditions) left the Gram matrix behind the packed weights: accumulate S1 only
     static const int gram_env = getenv("HYB_S1_GRAM") ? atoi(getenv("HYB_S1_GRAM")) : 1;
-    const bool saved_g = gram_env && wave_private && training && packed_in != nullptr;
+    const bool saved_g = gram_env && wave_private && training && packed_in != nullptr && sizeof(T) == 2;    // (the Gram pass is 16-bit only)
     const long long rw = saved_g ? (long long)Cop * 48 : roww;
     int rc = wave_private ? hyb_stage1w_bwd(dtype, a, saved_g ? 0 : 1, gx, st) : s1_dispatch<T, 4>(a, gx, st);
     if (rc) return rc;

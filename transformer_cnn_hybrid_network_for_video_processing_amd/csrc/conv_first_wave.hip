@@ -45,6 +45,20 @@ __device__ __forceinline__ void s1w_store8(__amdgpu_buffer_rsrc_t rs, unsigned v
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o.b), rs, voff, 16, 0);      // soffset is outside the range check: an out-of-range voff stays out of range
 }
 
+// pre-split forms (split-bf16 build, hyb_common.h): a whole fragment in place; two pre-split pixel quads -> one pre-split fragment
+__device__ __forceinline__ void s1w_presplit_frag(Frag<float>& f) {
+    f32x4 a = {f.v[0], f.v[1], f.v[2], f.v[3]}, b = {f.v[4], f.v[5], f.v[6], f.v[7]};
+    hyb_presplit8(a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+}
+__device__ __forceinline__ void s1w_presplit_frag(Frag<bf16>&) {}
+__device__ __forceinline__ void s1w_quads_to_frag(Frag<float>& f, const Quad<float>& q0, const Quad<float>& q1) {
+    f.v[0] = q0.v[0]; f.v[1] = q0.v[1]; f.v[2] = q1.v[0]; f.v[3] = q1.v[1];      // hi halves of the two pixels
+    f.v[4] = q0.v[2]; f.v[5] = q0.v[3]; f.v[6] = q1.v[2]; f.v[7] = q1.v[3];      // lo halves
+}
+__device__ __forceinline__ void s1w_quads_to_frag(Frag<bf16>&, const Quad<bf16>&, const Quad<bf16>&) {}
+
 #ifndef S1W_SB_UNROLL
 #define S1W_SB_UNROLL 2
 #endif
@@ -64,6 +78,9 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
     const int H = a.H, W = a.W, Ci = a.Ci, Cop = a.Cop;
     const int Ho = H >> 1, Wo = W >> 1;
     const T* wp = (const T*)a.wp2;                                             // the wave kernels' own K order (s1w_pack_kernel)
+    // split-bf16 build, fp32 storage: the image holds pre-split pixel quads (hyb_presplit4, written once when a pixel is staged; every
+    // pixel feeds ~6 fragments) and the weight fragments are split once per kernel: no conversions in the block loop
+    constexpr bool PRESPLIT = HYB_X3 && sizeof(T) == 4;
 
     Frag<T> w0[NT], w1[NT];
 #pragma unroll
@@ -71,6 +88,7 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
         const T* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
         frag_load(w0[t], row);
         frag_load(w1[t], row + 32);
+        if constexpr (PRESPLIT) { s1w_presplit_frag(w0[t]); s1w_presplit_frag(w1[t]); }
     }
     f32x2 c_sc[NT][2], c_sh[NT][2];
     if (MODE == 1) {
@@ -150,6 +168,7 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
                 Quad<T> qv;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) qv.v[c] = from_f32<T>(pf[c][i]);
+                if constexpr (PRESPLIT) hyb_presplit4(qv.v);
                 *reinterpret_cast<Quad<T>*>(img + st_lds + i * 4) = qv;
             }
         }
@@ -180,17 +199,19 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
                     const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + f_k0 + joff + 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { b0.v[c] = lo.v[c]; b0.v[4 + c] = hi.v[c]; }
+                    if constexpr (PRESPLIT) s1w_quads_to_frag(b0, lo, hi);
                 }
                 {
                     const Quad<T> lo = *reinterpret_cast<const Quad<T>*>(img + f_k1 + joff);
                     const Quad<T> hi = *reinterpret_cast<const Quad<T>*>(img + f_k1 + joff + 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { b1.v[c] = lo.v[c]; b1.v[4 + c] = hi.v[c]; }
+                    if constexpr (PRESPLIT) s1w_quads_to_frag(b1, lo, hi);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[j][t] = mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
-                    acc[j][t] = mma32(w1[t], b1, acc[j][t]);
+                    acc[j][t] = PRESPLIT ? mma32_pre(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f}) : mma32(w0[t], b0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    acc[j][t] = PRESPLIT ? mma32_pre(w1[t], b1, acc[j][t]) : mma32(w1[t], b1, acc[j][t]);
                 }
             }
             if (MODE == 0) {
@@ -540,6 +561,279 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     }
 }
 
+#ifdef HYB_F32_X3
+// ---- the same backward pass for the split-bf16 build (fp32 storage outside, "bf16x3" mode): everything a wave parks in LDS exists as
+// TWO bf16 planes, hi = bf16(v) and lo = bf16(v - hi) -- the halo image (split once when a pixel is staged), the routed gradient dz
+// (split once when parked), the constant table -- so the transposing 16-bit reads work unchanged on either plane and every product is the
+// three MFMAs lo*hi + hi*lo + hi*hi of hyb_common.h's mma32, with no conversion in any inner loop.  The lo plane sits S1X_PLS elements
+// behind the hi plane.  No saved Gram matrix in this mode (the forward pass takes the statistics pass): always accumulates S1 and G.
+__device__ __forceinline__ f32x4 s1x_mma3(const Frag<bf16>& ah, const Frag<bf16>& al, const Frag<bf16>& bh, const Frag<bf16>& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, c, 0, 0, 0);      // small terms first (as mma32)
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void s1x_quads(Frag<bf16>& f, const bf16* p) {   // two horizontally adjacent pixel quads = one fragment
+    const Quad<bf16> lo = *reinterpret_cast<const Quad<bf16>*>(p);
+    const Quad<bf16> hi = *reinterpret_cast<const Quad<bf16>*>(p + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { f.v[c] = lo.v[c]; f.v[4 + c] = hi.v[c]; }
+}
+
+template <int NT, int CI>
+__global__ __launch_bounds__(256) void stage1w_bwd_x3_kernel(S1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int DS = NT * 16 + 8;
+    constexpr int PLS = S1W_IMG + 64 * DS + S1B_CT;                            // one plane of a wave's slice (elements)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16* img0 = reinterpret_cast<bf16*>(smem_raw) + wave * (2 * PLS);         // hi plane; + PLS = lo plane
+    bf16* dyt = img0 + S1W_IMG;
+    bf16* ctab = dyt + 64 * DS;
+    const int p = lane & 15, q = lane >> 4, wy = p >> 2, wx = p & 3;
+    const int pp = lane & 3, qq = (lane & 15) >> 2;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int H = a.H, W = a.W, Ci = a.Ci, Cop = a.Cop;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const float* wp = (const float*)a.wp2;
+
+    if (lane < S1B_CT) { ctab[lane] = (bf16)(lane == 0 ? 1.f : 0.f); ctab[PLS + lane] = (bf16)0.f; }
+    Frag<bf16> w0h[NT], w0l[NT], w1h[NT], w1l[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* row = wp + (long long)(co_base + (p >> 2) * (NT * 4) + t * 4 + (p & 3)) * S1_KP + 8 * q;
+        Frag<float> f;
+        frag_load(f, row);      hyb_split_bf16(f, w0h[t].v, w0l[t].v);
+        frag_load(f, row + 32); hyb_split_bf16(f, w1h[t].v, w1l[t].v);
+    }
+    f32x2 c_sc[NT][2], c_sh[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = co_base + q * (NT * 4) + t * 4 + r;
+            c_sc[t][r >> 1][r & 1] = a.ss[ch]; c_sh[t][r >> 1][r & 1] = a.ss[Cop + ch];
+        }
+    f32x4 wacc[3][NT], gacc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int bx_n = a.tilesX, by_n = a.tilesY, bpi = bx_n * by_n;
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    const int chunk = (a.numTiles + nwaves - 1) / nwaves;
+    const int blk_begin = gw * chunk < a.numTiles ? gw * chunk : a.numTiles;
+    const int blk_end = blk_begin + chunk < a.numTiles ? blk_begin + chunk : a.numTiles;
+    const int nblk = blk_end - blk_begin;
+
+    const int hrow = lane / 6, hseg = lane - hrow * 6;
+    const bool hlane = lane < 60;
+    const unsigned ld_lane = (unsigned)((hrow * W + 4 * hseg) * 4);
+    const unsigned st_lds = (unsigned)((s1w_rowoff(hrow) + 4 * hseg) * 4);
+    const unsigned plane = (unsigned)(H * W) * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = hyb_rsrc(a.x, (unsigned)((long long)a.N * Ci * H * W * 4));
+    const __amdgpu_buffer_rsrc_t drs = hyb_rsrc(a.dp, (unsigned)((long long)a.N * Ho * Wo * Cop * 4));
+    const unsigned OOB = 0xFFFFFFF0u;
+    int f_k0[2], f_k1[2];
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+        f_k0[jy] = (s1w_rowoff(2 * wy + jy + (q < 3 ? q : 0)) + 2 * wx + 3 + (q < 3 ? 0 : 2)) * 4;
+        f_k1[jy] = (s1w_rowoff(2 * wy + jy + (q == 0 ? 1 : 2)) + 2 * wx + 3 + 2) * 4;
+    }
+    const unsigned dp_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * 4);
+    const int pix_col = 4 * (q & 1) + qq + 3;
+    int boff[3];
+    bool bconst[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        const int tap = 4 * kt + pp;
+        bconst[kt] = tap >= 9;
+        boff[kt] = tap < 9 ? (s1w_rowoff((q >> 1) + tap / 3) + pix_col + tap % 3) * 4 : (tap - 9) * 4;
+    }
+    const int a_lo = (4 * q + qq) * DS + 4 * pp;
+
+    int n_c = blk_begin / bpi, by_c, bx_c;
+    { const int rem = blk_begin - n_c * bpi; by_c = rem / bx_n; bx_c = rem - by_c * bx_n; }
+    n_c = __builtin_amdgcn_readfirstlane(n_c); by_c = __builtin_amdgcn_readfirstlane(by_c); bx_c = __builtin_amdgcn_readfirstlane(bx_c);
+    int n_n = n_c, by_n_ = by_c, bx_n_ = bx_c;
+    auto advance = [&](int& n, int& by, int& bx) {
+        ++bx;
+        if (bx == bx_n) { bx = 0; ++by; if (by == by_n) { by = 0; ++n; } }
+    };
+    f32x4 pf[4];
+    Vec8<float> gpf[2][NT / 2];
+    auto prefetch = [&](int n, int by, int bx) {
+        const int row0 = by * 8 - 1, col0 = bx * S1W_BW - 4;
+        const unsigned bo = (unsigned)((((long long)n * Ci * H + row0) * W + col0) * 4);
+        const bool ok = hlane && (unsigned)(row0 + hrow) < (unsigned)H && (unsigned)(col0 + 4 * hseg) <= (unsigned)(W - 4);
+        const unsigned voff = ok ? ld_lane + bo : OOB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (CI ? c < CI : c < Ci) pf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * plane, 0));
+            else pf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned dbase = (unsigned)((((long long)n * Ho + by * 4) * Wo + bx * (S1W_BW / 2)) * Cop * 4) + dp_lane;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) {
+                const unsigned off = dbase + (unsigned)((sb * 4 * Cop + h8 * 8) * 4);
+                gpf[sb][h8].a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+                gpf[sb][h8].b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 16, 0));
+            }
+    };
+    auto stage = [&](bf16* img) {
+        if (hlane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Quad<bf16> qh, ql;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float x = pf[c][i]; qh.v[c] = (bf16)x; ql.v[c] = (bf16)(x - (float)qh.v[c]); }
+                *reinterpret_cast<Quad<bf16>*>(img + st_lds + i * 4) = qh;
+                *reinterpret_cast<Quad<bf16>*>(img + PLS + st_lds + i * 4) = ql;
+            }
+        }
+    };
+    if (nblk > 0) { prefetch(n_c, by_c, bx_c); stage(img0); advance(n_n, by_n_, bx_n_); }
+
+    for (int it = 0; it < nblk; ++it) {
+        const bf16* img = img0;
+        const bool more = it + 1 < nblk;
+        Vec8<float> gcur[2][NT / 2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) gcur[sb][h8] = gpf[sb][h8];
+        if (more) prefetch(n_n, by_n_, bx_n_);
+        int fx0[4] = {f_k0[0], f_k0[0] + 4, f_k0[1], f_k0[1] + 4}, fx1[4] = {f_k1[0], f_k1[0] + 4, f_k1[1], f_k1[1] + 4};
+        asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]), "+v"(fx0[3]), "+v"(fx1[3]));
+#pragma unroll 1
+        for (int sb = 0; sb < 2; ++sb) {
+            f32x4 acc[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int joff = 8 * sb * 4;
+                Frag<bf16> b0h, b0l, b1h, b1l;
+                s1x_quads(b0h, img + fx0[j] + joff); s1x_quads(b0l, img + PLS + fx0[j] + joff);
+                s1x_quads(b1h, img + fx1[j] + joff); s1x_quads(b1l, img + PLS + fx1[j] + joff);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[j][t] = s1x_mma3(w0h[t], w0l[t], b0h, b0l, f32x4{0.f, 0.f, 0.f, 0.f});
+                    acc[j][t] = s1x_mma3(w1h[t], w1l[t], b1h, b1l, acc[j][t]);
+                }
+            }
+#pragma unroll
+            for (int h8 = 0; h8 < NT / 2; ++h8) {
+                const Vec8<float> g = sb == 0 ? gcur[0][h8] : gcur[1][h8];
+                Vec8<bf16> oh[4], ol[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int t = h8 * 2 + (e2 >> 1), h = e2 & 1;
+                    const f32x2 sc = c_sc[t][h], sh = c_sh[t][h];
+                    f32x2 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = f32x2{acc[j][t][2 * h], acc[j][t][2 * h + 1]} * sc + sh;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = e2 * 2 + u;
+                        const float m = __builtin_fmaxf(__builtin_fmaxf(v[0][u], v[1][u]), __builtin_fmaxf(v[2][u], v[3][u]));
+                        const float dy = m > 0.f ? g.get(e) : 0.f;
+                        const bf16 dh = (bf16)dy, dl = (bf16)(dy - (float)dh);      // split once; routing only selects
+                        const bf16 z = (bf16)0.f;
+                        const bool e0 = v[0][u] == m, e1 = v[1][u] == m, e2b = v[2][u] == m;
+                        const bool s0 = e0, s1 = !e0 && e1, s2 = !e0 && !e1 && e2b, s3 = !e0 && !e1 && !e2b;
+                        oh[0].v[e] = s0 ? dh : z; ol[0].v[e] = s0 ? dl : z;
+                        oh[1].v[e] = s1 ? dh : z; ol[1].v[e] = s1 ? dl : z;
+                        oh[2].v[e] = s2 ? dh : z; ol[2].v[e] = s2 ? dl : z;
+                        oh[3].v[e] = s3 ? dh : z; ol[3].v[e] = s3 ? dl : z;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pix = (2 * wy + (j >> 1)) * 8 + 2 * wx + (j & 1);
+                    oh[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
+                    ol[j].store(dyt + PLS + pix * DS + q * (NT * 4) + h8 * 8);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<bf16> afh[NT], afl[NT], bfh[3], bfl[3];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const bf16* lo = dyt + ks * 32 * DS + a_lo + c * 16;
+                    S1BTr<bf16>::read(afh[c], lo, lo + 16 * DS);
+                    S1BTr<bf16>::read(afl[c], lo + PLS, lo + PLS + 16 * DS);
+                }
+                const int pstep = (2 * ks * S1W_PAIR + 8 * sb) * 4;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const bf16* lo = bconst[kt] ? ctab + boff[kt] : img + boff[kt] + pstep;
+                    const bf16* hi = bconst[kt] ? lo : lo + S1W_PAIR * 4;
+                    S1BTr<bf16>::read(bfh[kt], lo, hi);
+                    S1BTr<bf16>::read(bfl[kt], lo + PLS, hi + PLS);
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) wacc[kt][c] = s1x_mma3(afh[c], afl[c], bfh[kt], bfl[kt], wacc[kt][c]);
+                }
+                if (blockIdx.y == 0) {
+                    gacc[0] = s1x_mma3(bfh[0], bfl[0], bfh[0], bfl[0], gacc[0]); gacc[1] = s1x_mma3(bfh[0], bfl[0], bfh[1], bfl[1], gacc[1]);
+                    gacc[2] = s1x_mma3(bfh[0], bfl[0], bfh[2], bfl[2], gacc[2]); gacc[3] = s1x_mma3(bfh[1], bfl[1], bfh[1], bfl[1], gacc[3]);
+                    gacc[4] = s1x_mma3(bfh[1], bfl[1], bfh[2], bfl[2], gacc[4]); gacc[5] = s1x_mma3(bfh[2], bfl[2], bfh[2], bfl[2], gacc[5]);
+                }
+            }
+        }
+        if (more) { stage(img0); advance(n_n, by_n_, bx_n_); }
+        advance(n_c, by_c, bx_c);
+    }
+
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);                           // [4][NT*16*48 + 2304]
+    constexpr int RW = NT * 16 * 48 + 2304;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * RW + (c * 16 + 4 * q + r) * 48 + kt * 16 + p] = wacc[kt][c][r];
+    auto put_g = [&](int i, int gi, int gj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * RW + NT * 16 * 48 + (gi * 16 + 4 * q + r) * 48 + gj * 16 + p] = gacc[i][r];
+    };
+    put_g(0, 0, 0); put_g(1, 0, 1); put_g(2, 0, 2); put_g(3, 1, 1); put_g(4, 1, 2); put_g(5, 2, 2);
+    __syncthreads();
+    const long long roww = (long long)Cop * 48 + 2304;
+    float* out = a.part + (long long)blockIdx.x * roww;
+    for (int i = tid; i < NT * 16 * 48; i += 256)
+        out[(long long)co_base * 48 + i] = (red[i] + red[RW + i]) + (red[2 * RW + i] + red[3 * RW + i]);
+    if (blockIdx.y == 0) {
+        for (int i = tid; i < 2304; i += 256) {
+            const int gr = i / 48, gc = i % 48;
+            const int o = NT * 16 * 48 + i;
+            out[(long long)Cop * 48 + i] = (gr / 16 <= gc / 16) ? (red[o] + red[RW + o]) + (red[2 * RW + o] + red[3 * RW + o]) : 0.f;
+        }
+    }
+}
+
+template <int NT>
+int s1x_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
+    constexpr int DS = NT * 16 + 8;
+    size_t lds = (size_t)4 * 2 * (S1W_IMG + 64 * DS + S1B_CT) * sizeof(bf16);
+    const size_t red = (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
+    if (red > lds) lds = red;
+    lds += 64;
+    dim3 grid(grid_x, a.Cop / (NT * 16));
+    if (lds > 64 * 1024) {
+        static HybAttrOnce once3, once0;
+        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_x3_kernel<NT, 3> : (const void*)stage1w_bwd_x3_kernel<NT, 0>, (int)lds)) return e;
+    }
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_x3_kernel<NT, 3>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_bwd_x3_kernel<NT, 0>), grid, dim3(256), lds, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+#endif  // HYB_F32_X3
+
 // ---- Gram pass: G = P^T P over all pixels (48 x 48, upper-triangle tiles), the im2col patches read as in the backward kernel.
 // G depends on the frames only.  It serves the BatchNorm batch statistics (column 36 of P is all ones: G[k][36] = sum P[k], and
 //   sum_pix y_co = w_co . G[:,36],   sum_pix y_co^2 = w_co^T G w_co      -- no conv, no per-pixel squares: 12 MFMAs and no vector
@@ -714,12 +1008,15 @@ int hyb_stage1w_pack(int dtype, const float* weight, void* wp2, int Co, int Ci, 
 // backward pass over 8x16 blocks; `a` as for the block-level MODE 4 launch (wp2 set); bf16 only (the transposing LDS read is a 16-bit
 // instruction): fp32 parity mode keeps the block-level kernel
 int hyb_stage1w_bwd(int dtype, S1Args a, int with_g, int& grid_x, hipStream_t st) {
-    if (dtype != HYB_BF16) return HYB_E_ARG;
+    if (dtype != HYB_BF16 && !(HYB_X3 && dtype == HYB_F32 && with_g)) return HYB_E_ARG;
     a.tilesX = hyb_cdiv(a.W, S1W_BW); a.tilesY = hyb_cdiv(a.H, 8);
     const long long nb = (long long)a.N * a.tilesX * a.tilesY;
     if (nb >= (1ll << 30)) return HYB_E_ARG;
     a.numTiles = (int)nb;
     if ((long long)grid_x * 4 > nb) grid_x = (int)((nb + 3) / 4);
+#ifdef HYB_F32_X3
+    if (dtype == HYB_F32) return a.Cop % 64 == 0 ? s1x_bwd_launch<4>(a, grid_x, st) : s1x_bwd_launch<2>(a, grid_x, st);
+#endif
     if (a.Cop % 64 == 0) return with_g ? s1w_bwd_launch<bf16, 4, true>(a, grid_x, st) : s1w_bwd_launch<bf16, 4, false>(a, grid_x, st);
     return with_g ? s1w_bwd_launch<bf16, 2, true>(a, grid_x, st) : s1w_bwd_launch<bf16, 2, false>(a, grid_x, st);
 }

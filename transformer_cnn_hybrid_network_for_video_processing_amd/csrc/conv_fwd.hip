@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
     constexpr int PHP = TileGeom<PG>::PHP, PWP = TileGeom<PG>::PWP;
     constexpr int TH = 4 * PHP, TW = 4 * PWP, HH = TH + 2, HW_ = TW + 2, HP = HH * HW_;
     constexpr int MT = 8;
+    // split-bf16 build, fp32 storage: the halo image and the packed weights hold pre-split fragments (hyb_common.h) -- the image is split
+    // once when staged instead of once per tap and wave, the weights once per step by the pack kernels
+    constexpr bool PRESPLIT = HYB_X3 && sizeof(T) == 4;
     constexpr int SPF = CK / 8;                            // 8-channel fragment slots per halo pixel
     constexpr int NCHUNK = CK / 32;
     static_assert(HW_ % 4 == 2, "swizzle derivation assumes halo width = 2 mod 4");
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                 v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + cb0 + 8 * s);
             else
                 v.zero();
+            if constexpr (PRESPLIT) v.presplit();
             v.store(halo + hp * CK + ((s ^ halo_swz(hp, hy, SPF)) << 3));
         }
     };
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                 const T* wbase[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wbase[t] = wlane[t] + (long long)(cblk * NCHUNK + chunk) * (9 * 32);
-                constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;      // bf16: prefetch the next tap's weights; fp32: single buffer
+                constexpr int NBUF = (sizeof(T) == 2 || PRESPLIT) ? 2 : 1;      // bf16 / pre-split: prefetch the next tap's weights; exact fp32: single buffer
                 Frag<T> a[NBUF][NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) frag_load(a[0][t], wbase[t]);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_kernel(const T* __restric
                         Frag<T> b;
                         frag_load(b, bptr + ((patch_row<PG>(0, m) * 4) * HW_ + patch_col<PG>(m) * 4) * CK);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[m][t] = mma32(a[tap % NBUF][t], b, acc[m][t]);
+                        for (int t = 0; t < NT; ++t) acc[m][t] = PRESPLIT ? mma32_pre(a[tap % NBUF][t], b, acc[m][t]) : mma32(a[tap % NBUF][t], b, acc[m][t]);
                     }
                 }
             }
@@ -406,6 +410,13 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
     }
 }
 
+// one packed element; split-bf16 build with fp32 storage: the 3x3 layouts (not the first layer's) are stored pre-split for conv3x3_nhwc_kernel
+__device__ __forceinline__ void pack_store(bf16* wp, long long i, float v, bool) { wp[i] = (bf16)v; }
+__device__ __forceinline__ void pack_store(float* wp, long long i, float v, bool presplit) {
+    if (HYB_X3 && presplit) hyb_presplit_store(wp, i, v);
+    else wp[i] = v;
+}
+
 // w fp32 [Co,Ci,3,3] -> packed T (see hybrid_hip.h for the three modes); padded rows/cols are zero.
 template <typename T>
 __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __restrict__ wp, int Co, int Ci, int Cop, int Cip,
@@ -432,7 +443,7 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, T* __r
         const int co = (int)(i / 32);
         if (co < Co && k < 9 * Ci) { const int tap = k / Ci, ci = k - tap * Ci; v = w[((long long)co * Ci + ci) * 9 + tap]; }
     }
-    wp[i] = from_f32<T>(v);
+    pack_store(wp, i, v, mode != 2);
 }
 
 // stats[2][Cop] = sum over the G per-workgroup partial rows, fixed order
@@ -590,13 +601,13 @@ __global__ void pack_weight_dual_kernel(const float* __restrict__ w, T* __restri
         const int co = (int)(k / ((long long)9 * Cip));
         const int ci = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
-        wp0[k] = from_f32<T>(v);
+        pack_store(wp0, k, v, true);
     } else {
         const int chunk = (int)((k / 288) % (Cop / 32));
         const int ci = (int)(k / ((long long)9 * Cop));
         const int co = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
-        wp1[k] = from_f32<T>(v);
+        pack_store(wp1, k, v, true);
     }
 }
 int hyb_conv_pack_weight_dual(int dtype, const float* w, void* wp0, void* wp1, int Co, int Ci, int Cop, int Cip, hipStream_t st) {
@@ -641,13 +652,13 @@ __global__ void pack_weight_many_kernel(PackMany a) {
         const int co = (int)(k / ((long long)9 * Cip));
         const int ci = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + tap];
-        ((T*)a.wp0[s])[k] = from_f32<T>(v);
+        pack_store((T*)a.wp0[s], k, v, true);
     } else {
         const int chunk = (int)((k / 288) % (Cop / 32));
         const int ci = (int)(k / ((long long)9 * Cop));
         const int co = chunk * 32 + c32;
         if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * 9 + (8 - tap)];
-        ((T*)a.wp1[s])[k] = from_f32<T>(v);
+        pack_store((T*)a.wp1[s], k, v, true);
     }
 }
 // s1_wp != NULL: also the first stage's two layouts (s1_w [s1_Co][s1_Ci][3][3] -> s1_wp [2][s1_Cop][64])

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
                 Vec8<T> v;
                 if (gy < H && gx < W && co0 + 8 * s < Cop) v.load(dy + ((long long)(n * H + gy) * W + gx) * Cop + co0 + 8 * s);
                 else v.zero();
+                v.epack();
                 v.store(dyt + pix * DY_STRIDE + 8 * s);
             }
         } else {
@@ -153,9 +154,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ly = 2 * wyy + (j >> 1), lx = 2 * wxx + (j & 1);
-                o[j].store(dyt + (ly * WG_TW + lx) * DY_STRIDE + 8 * oct);
                 if (writer && pv[j])
                     o[j].store((T*)fz.dyraw_out + ((long long)(n * H + ty0 + ly) * W + tx0 + lx) * Cop + co0 + 8 * oct);
+                o[j].epack();                       // (split-bf16 build: the LDS tiles are element-packed, hyb_common.h; else a no-op)
+                o[j].store(dyt + (ly * WG_TW + lx) * DY_STRIDE + 8 * oct);
             }
         }
         // stage x halo: 180 pixels x XCOLS channels
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
             Vec8<T> v;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) v.load(x + ((long long)(n * H + gy) * W + gx) * Cip + ci0 + 8 * s);
             else v.zero();
+            v.epack();
             v.store(xh + hp * X_STRIDE + 8 * s);
         }
         __syncthreads();
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const T* __restrict_
                 Frag<T> b;
                 tr_frag(b, xh + ((2 * ks + kh) * WG_HW + 4 * g + kw) * X_STRIDE + cit * 16, X_STRIDE, WG_HW, lane);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[tap][c] = mma32(a[c], b, acc[tap][c]);
+                for (int c = 0; c < NCT; ++c) acc[tap][c] = mma32_e(a[c], b, acc[tap][c]);
             }
         }
     }
@@ -689,7 +692,8 @@ inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
     const long long numTiles = (long long)N * hyb_cdiv(H, WG_TH) * hyb_cdiv(W, WG_TW);
     if (first) { p.cit = 0; p.gy = Cop / 32; p.per_slab = (long long)Cop * 32; }
     else { p.cit = (Cip % 64 == 0) ? 4 : 2; p.gy = ((Cop + 63) / 64) * (Cip / (p.cit * 16)); p.per_slab = (long long)Cop * 9 * Cip; }
-    long long s = 512 / p.gy;
+    static const int wgs = getenv("HYB_WGRAD1_WGS") ? atoi(getenv("HYB_WGRAD1_WGS")) : 512;       // first-generation kernel: workgroups in total (A/B)
+    long long s = (wgs > 0 ? wgs : 512) / p.gy;
     if (s < 1) s = 1;
     if (s > numTiles) s = numTiles;
     p.S = (int)s;

@@ -85,13 +85,83 @@ __device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& 
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
+// PRE-SPLIT operand storage: where a kernel reads the same fragment many times (a staged image read by nine taps, packed weights),
+// the 32 bytes of eight fp32 values hold [hi bf16 x 8][lo bf16 x 8] instead -- written once by whoever stages / packs the operand
+// (hyb_presplit8), consumed without any vector arithmetic (mma32_pre).  Same hi / lo values and the same three MFMAs in the same order as
+// mma32: results are bit-identical.
+constexpr bool HYB_X3 = true;
+__device__ __forceinline__ void hyb_presplit8(f32x4& a, f32x4& b) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (bf16)a[j]; lo[j] = (bf16)(a[j] - (float)hi[j]); hi[4 + j] = (bf16)b[j]; lo[4 + j] = (bf16)(b[j] - (float)hi[4 + j]); }
+    a = __builtin_bit_cast(f32x4, hi);
+    b = __builtin_bit_cast(f32x4, lo);
+}
+__device__ __forceinline__ f32x4 mma32_pre(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, f32x4{a.v[0], a.v[1], a.v[2], a.v[3]}), al = __builtin_bit_cast(bf16x8, f32x4{a.v[4], a.v[5], a.v[6], a.v[7]});
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, f32x4{b.v[0], b.v[1], b.v[2], b.v[3]}), bl = __builtin_bit_cast(bf16x8, f32x4{b.v[4], b.v[5], b.v[6], b.v[7]});
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+// one element of a pre-split fp32 buffer: element i of the logical array lives in the 8-group i >> 3 as halves (i & 7) and 8 + (i & 7)
+__device__ __forceinline__ void hyb_presplit_store(float* base, long long i, float v) {
+    const bf16 hi = (bf16)v, lo = (bf16)(v - (float)hi);
+    unsigned short* h = reinterpret_cast<unsigned short*>(base) + (i >> 3) * 16 + (i & 7);
+    h[0] = __builtin_bit_cast(unsigned short, hi);
+    h[8] = __builtin_bit_cast(unsigned short, lo);
+}
+// four fp32 values (one pixel's channel quad, 16 bytes) -> the same 16 bytes holding [hi bf16 x 4][lo bf16 x 4]; two such quads q0, q1 of
+// horizontally adjacent pixels make the pre-split fragment {q0.hi, q1.hi | q0.lo, q1.lo} by register naming alone (conv_first_wave.hip)
+__device__ __forceinline__ void hyb_presplit4(float (&v)[4]) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (bf16)v[j]; lo[j] = (bf16)(v[j] - (float)hi[j]); }
+    const f32x2 h = __builtin_bit_cast(f32x2, hi), l = __builtin_bit_cast(f32x2, lo);
+    v[0] = h[0]; v[1] = h[1]; v[2] = l[0]; v[3] = l[1];
+}
+// ELEMENT-PACKED operand storage, for kernels that gather a fragment's eight values from eight places (transposing reads of a staged
+// image, conv_wgrad.hip / conv_first.hip): every fp32 LDS word holds (bits of hi) << 16 | bits of lo.  hyb_epack once per staged element;
+// mma32_e rebuilds the two bf16 fragments with byte permutes instead of conversions and subtractions.  Same values, same MFMAs.
+__device__ __forceinline__ float hyb_epack(float x) {
+    const bf16 hi = (bf16)x, lo = (bf16)(x - (float)hi);
+    return __builtin_bit_cast(float, ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo));
+}
+__device__ __forceinline__ void hyb_eunpack(const Frag<float>& f, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned u = __builtin_bit_cast(unsigned, f.v[j]);
+        hi[j] = __builtin_bit_cast(bf16, (unsigned short)(u >> 16));
+        lo[j] = __builtin_bit_cast(bf16, (unsigned short)(u & 0xffffu));
+    }
+}
+__device__ __forceinline__ f32x4 mma32_e(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+    bf16x8 ah, al, bh, bl;
+    hyb_eunpack(a, ah, al);
+    hyb_eunpack(b, bh, bl);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
 #else
+constexpr bool HYB_X3 = false;
 __device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
     return c;
 }
+// (only the split-bf16 build stores pre-split operands; these keep the shared kernel sources compiling)
+__device__ __forceinline__ void hyb_presplit8(f32x4&, f32x4&) {}
+__device__ __forceinline__ f32x4 mma32_pre(const Frag<float>& a, const Frag<float>& b, f32x4 c) { return mma32(a, b, c); }
+__device__ __forceinline__ void hyb_presplit_store(float* base, long long i, float v) { base[i] = v; }
+__device__ __forceinline__ void hyb_presplit4(float (&)[4]) {}
+__device__ __forceinline__ float hyb_epack(float x) { return x; }
+__device__ __forceinline__ f32x4 mma32_e(const Frag<float>& a, const Frag<float>& b, f32x4 c) { return mma32(a, b, c); }
 #endif
+__device__ __forceinline__ void hyb_presplit4(bf16 (&)[4]) {}
+__device__ __forceinline__ bf16 hyb_epack(bf16 x) { return x; }
+__device__ __forceinline__ f32x4 mma32_e(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) { return mma32(a, b, c); }
+__device__ __forceinline__ f32x4 mma32_pre(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) { return mma32(a, b, c); }
 
 // load a fragment from 8 consecutive T (16-byte aligned for bf16, 16-byte aligned for fp32)
 __device__ __forceinline__ void frag_load(Frag<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const bf16x8*>(p); }
@@ -123,6 +193,8 @@ template <> struct Vec8<bf16> {
     __device__ __forceinline__ void store_nt(bf16* p) const { __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p)); }
     __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
     __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16)x; }
+    __device__ __forceinline__ void presplit() {}
+    __device__ __forceinline__ void epack() {}
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (bf16)0.0f;
@@ -141,6 +213,11 @@ template <> struct Vec8<float> {
     __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
     __device__ __forceinline__ void set(int j, float x) { if (j < 4) a[j] = x; else b[j - 4] = x; }
     __device__ __forceinline__ void zero() { a = f32x4{0, 0, 0, 0}; b = f32x4{0, 0, 0, 0}; }
+    __device__ __forceinline__ void epack() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = hyb_epack(a[j]); b[j] = hyb_epack(b[j]); }
+    }
+    __device__ __forceinline__ void presplit() { hyb_presplit8(a, b); }          // split-bf16 build only (hyb_presplit8); zeros stay zeros
 };
 
 // ---------------------------------------------------------------------------------------
