@@ -7,6 +7,10 @@
 #include "hyb_common.h"
 
 size_t hyb_encoder_xin_offset(int dtype, int B, int S, int D, int Hid, int H);
+int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
+                         const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
+                         unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
+                         const HybDwExtra* extra);
 int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                            int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
@@ -175,9 +179,14 @@ extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* to
     void* dtok = ws + enc_ws + al256((size_t)N * D * es);       // d(tokens)
     void* dfeat = ws + enc_ws + 2 * al256((size_t)N * D * es);  // d(frame features), padded channels zero
     HYB_TRY(hyb_head_bwd(dtype, enc_out, head_w, dlogits, denc, dhead_w, dhead_b, B, S, D, classes, stream));
-    HYB_TRY(hyb_encoder_bwd(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws, enc_ws, stream));
+    // the token projection's weight gradient (dtok^T feat) rides in the encoder backward's final multi-matrix launch
+    const bool ride = C % 8 == 0;
+    const HybDwExtra tokdw{dtok, feat, dtoken_w, dtoken_b, D, C, D, Cp};
+    HYB_TRY(hyb_encoder_bwd_impl(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws,
+                                 enc_ws, stream, ride ? &tokdw : nullptr));
     if (Cp > C) { hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)N * Cp * es, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
-    HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, dtoken_w, dtoken_b, N, D, C, 0, nullptr, 0, stream));
+    HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, ride ? nullptr : dtoken_w, ride ? nullptr : dtoken_b, N, D, C, 0, nullptr, 0,
+                           stream));
     HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));
     return 0;
 }

@@ -60,6 +60,9 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 //         reduction order inside the 32-step is permuted but identical for A and B.
 // C/D: lane l holds column (l & 15), rows 4*(l >> 4) + r, r = 0..3.
 // ---------------------------------------------------------------------------------------
+// one more Linear weight (+ bias) gradient for the encoder backward's final multi-matrix launch (hyb_encoder_bwd_impl): dW[N][K] = dy^T x
+struct HybDwExtra { const void* dy; const void* x; float* dW; float* db; int N, K, lddy, ldx; };
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };

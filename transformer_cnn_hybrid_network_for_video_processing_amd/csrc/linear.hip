@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
         }
 }
 
-// Weight (+ bias) gradients of up to 6 Linear layers with DIFFERENT shapes in one launch (the six matrices of an encoder layer):
+// Weight (+ bias) gradients of up to 13 Linear layers with DIFFERENT shapes in one launch (the six matrices of each of two encoder layers
+// and the frame-token projection):
 //   dW_g[n][k] = sum_m dym_g[m][n] * x_g[m][k],   db_g[n] = sum_m dym_g[m][n],   dym_g = dy_g * (mask_g > 0) (mask optional).
 // Flat grid: workgroup -> (group, 64x64 tile) through the groups' tile offsets.
 struct DwGroup {
@@ -152,10 +153,12 @@ struct DwGroup {
     int N, K, lddy, ldx;       // dW is [N][K]; dy rows have lddy elements, x rows ldx
     int tiles_x, tile_begin;
 };
+constexpr int DW_MAX_GROUPS = 13;          // two encoder layers' six matrices + the frame-token projection
 struct DwArgs {
-    DwGroup g[6]; int ngroups, M;
-    // optional rider (the encoder backward's LayerNorm-affine gradients): blocks past `tiles` sum ln_rows partial rows of 2*ln_D floats
-    int tiles; const float* ln_part; int ln_rows, ln_D; float* ln_dgamma; float* ln_dbeta;
+    DwGroup g[DW_MAX_GROUPS]; int ngroups, M;
+    // optional riders (the encoder backward's LayerNorm-affine gradients, one per layer): blocks past `tiles` sum ln_rows partial rows of
+    // 2*ln_D floats each
+    int tiles, nriders; const float* ln_part[2]; int ln_rows, ln_D; float* ln_dgamma[2]; float* ln_dbeta[2];
 };
 
 template <typename T>
@@ -164,9 +167,11 @@ __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
     __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
     __shared__ __attribute__((aligned(16))) T Bs[BM * LDS_ROW];
     if ((int)blockIdx.x >= args.tiles) {                   // rider: column c of the LayerNorm partial rows, fixed order, eight loads in flight
-        const int c = ((int)blockIdx.x - args.tiles) * 256 + (int)threadIdx.x;
+        const int per = (2 * args.ln_D + 255) / 256;
+        const int rid = ((int)blockIdx.x - args.tiles) / per;
+        const int c = (((int)blockIdx.x - args.tiles) - rid * per) * 256 + (int)threadIdx.x;
         if (c >= 2 * args.ln_D) return;
-        const float* col = args.ln_part + c;
+        const float* col = args.ln_part[rid] + c;
         const long long ld = 2LL * args.ln_D;
         float s = 0.f;
         int r = 0;
@@ -178,12 +183,12 @@ __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
             for (int j = 0; j < 8; ++j) s += v[j];
         }
         for (; r < args.ln_rows; ++r) s += col[(long long)r * ld];
-        if (c < args.ln_D) args.ln_dgamma[c] = s; else args.ln_dbeta[c - args.ln_D] = s;
+        if (c < args.ln_D) args.ln_dgamma[rid][c] = s; else args.ln_dbeta[rid][c - args.ln_D] = s;
         return;
     }
     int gi = 0;
 #pragma unroll
-    for (int i = 1; i < 6; ++i)
+    for (int i = 1; i < DW_MAX_GROUPS; ++i)
         if (i < args.ngroups && (int)blockIdx.x >= args.g[i].tile_begin) gi = i;
     const DwGroup grp = args.g[gi];
     const int local = blockIdx.x - grp.tile_begin;
@@ -694,8 +699,8 @@ int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const vo
 // Internal: weight + bias gradients of up to 6 Linear layers of different shapes in one launch (see gemm_dw_multi_kernel).
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
-                        const float* ln_part, int ln_rows, int ln_D, float* ln_dgamma, float* ln_dbeta) {
-    if (groups < 1 || groups > 6 || M < 1) return HYB_E_ARG;
+                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta) {
+    if (groups < 1 || groups > DW_MAX_GROUPS || M < 1 || nriders < 0 || nriders > 2) return HYB_E_ARG;
     DwArgs a{};
     int tiles = 0;
     for (int i = 0; i < groups; ++i) {
@@ -706,9 +711,10 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
     }
     a.ngroups = groups; a.M = M; a.tiles = tiles;
     int blocks = tiles;
-    if (ln_part && ln_rows > 0 && ln_D > 0 && ln_dgamma && ln_dbeta) {
-        a.ln_part = ln_part; a.ln_rows = ln_rows; a.ln_D = ln_D; a.ln_dgamma = ln_dgamma; a.ln_dbeta = ln_dbeta;
-        blocks += hyb_cdiv(2 * ln_D, 256);
+    if (nriders > 0 && ln_part && ln_rows > 0 && ln_D > 0 && ln_dgamma && ln_dbeta) {
+        a.nriders = nriders; a.ln_rows = ln_rows; a.ln_D = ln_D;
+        for (int r = 0; r < nriders; ++r) { a.ln_part[r] = ln_part[r]; a.ln_dgamma[r] = ln_dgamma[r]; a.ln_dbeta[r] = ln_dbeta[r]; }
+        blocks += nriders * hyb_cdiv(2 * ln_D, 256);
     }
     if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, st, a);

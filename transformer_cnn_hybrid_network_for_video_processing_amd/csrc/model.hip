@@ -20,7 +20,7 @@ int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const fl
 int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
-                        const float* ln_part = nullptr, int ln_rows = 0, int ln_D = 0, float* ln_dgamma = nullptr, float* ln_dbeta = nullptr);
+                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
@@ -288,9 +288,23 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
     return 0;
 }
 
+int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
+                         const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
+                         unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
+                         const HybDwExtra* extra);
 extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                                const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                                unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
+    return hyb_encoder_bwd_impl(dtype, dout, mask, params, grads, saved, dx, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, workspace,
+                                workspace_bytes, stream, nullptr);
+}
+// extra != NULL: one more weight gradient whose dy is this function's dx (the frame-token projection of hyb_temporal_bwd) rides in the last
+// multi-matrix launch.  With L <= 2 the weight gradients of ALL layers are that one launch at the end (each layer's operands live in its own
+// parity set of the workspace until then): every dependent launch costs >= 4.6 us, and two 768-tile launches fill the chip worse than one.
+int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
+                         const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
+                         unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
+                         const HybDwExtra* extra) {
     HYB_CHECK_ARG(dout && params && grads && saved && dx && workspace && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     if (workspace_bytes < hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) return HYB_E_WORKSPACE;
@@ -324,6 +338,10 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
     // (The layer's weight-gradient launch is off the dX chain; issuing it as a parallel branch of the replayed graph was measured in
     // round 2 and lost 4.7 % of the step -- every fork / join edge costs more than the 5 us kernel it hides -- so it stays in line.)
 
+    const bool defer = L <= 2;                              // (two parity sets: the operands of both layers stay valid until the end)
+    const void* d_dy[13]; const void* d_mk[13]; const void* d_x[13]; float* d_dW[13]; float* d_db[13];
+    int d_N[13], d_K[13], d_lddy[13], d_ldx[13], nd = 0;
+    const float* d_ln[2] = {nullptr, nullptr}; float* d_lg[2] = {nullptr, nullptr}; float* d_lb[2] = {nullptr, nullptr};
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
         const char* base = sv + (size_t)i * lay.layer_bytes;
@@ -369,9 +387,28 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
             float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
             const int N_[6] = {D, Hid, D, D, D, D}, K_[6] = {Hid, D, D, D, D, D};
             const int lddy_[6] = {D, Hid, D, 3 * D, 3 * D, 3 * D}, ldx_[6] = {Hid, D, D, D, D, D};
-            HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, b.lnpart, 2 * lnrows, D, G[12], G[13]));
+            if (defer) {
+                const int o = nd * 6;
+                for (int j = 0; j < 6; ++j) {
+                    d_dy[o + j] = dy_[j]; d_mk[o + j] = mk_[j]; d_x[o + j] = x_[j]; d_dW[o + j] = dW_[j]; d_db[o + j] = db_[j];
+                    d_N[o + j] = N_[j]; d_K[o + j] = K_[j]; d_lddy[o + j] = lddy_[j]; d_ldx[o + j] = ldx_[j];
+                }
+                d_ln[nd] = b.lnpart; d_lg[nd] = G[12]; d_lb[nd] = G[13];
+                ++nd;
+            } else {
+                const float* lp[1] = {b.lnpart}; float* lg[1] = {G[12]}; float* lb[1] = {G[13]};
+                HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 1, lp, 2 * lnrows, D, lg, lb));
+            }
         }
         gA = gx;
     }
+    int ng = defer ? nd * 6 : 0;
+    if (extra) {
+        d_dy[ng] = extra->dy; d_mk[ng] = nullptr; d_x[ng] = extra->x; d_dW[ng] = extra->dW; d_db[ng] = extra->db;
+        d_N[ng] = extra->N; d_K[ng] = extra->K; d_lddy[ng] = extra->lddy; d_ldx[ng] = extra->ldx;
+        ++ng;
+    }
+    if (ng > 0)
+        HYB_TRY(hyb_linear_dw_multi(dtype, ng, d_dy, d_mk, d_x, d_dW, d_db, d_N, d_K, d_lddy, d_ldx, M, st, defer ? nd : 0, d_ln, 2 * lnrows, D, d_lg, d_lb));
     return 0;
 }
