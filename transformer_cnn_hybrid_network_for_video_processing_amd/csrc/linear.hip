@@ -468,6 +468,8 @@ struct ConvertArgs {
     void* Wt[18];
     int N[18], K[18];
     int ldt[18];             // row stride of the transposed copy (>= N; lets several transposes share one [K][sum N] buffer)
+    int tile_begin[19];      // vector kernel: flat grid, matrix g owns tiles [tile_begin[g], tile_begin[g+1]) of 64 x 64 (no empty workgroups)
+    int count;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
@@ -497,10 +499,13 @@ __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void convert_weights_vec_kernel(ConvertArgs a) {
     __shared__ float tile[64][65];
-    const int g = blockIdx.z;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 18; ++i)
+        if (i < a.count && (int)blockIdx.x >= a.tile_begin[i]) g = i;
     const int N = a.N[g], K = a.K[g];
-    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
-    if (n0 >= N || k0 >= K) return;
+    const int local = (int)blockIdx.x - a.tile_begin[g], tk = (K + 63) / 64;
+    const int n0 = (local / tk) * 64, k0 = (local % tk) * 64;
     const float* W = a.W[g];
     T* Wc = (T*)a.Wc[g];
     T* Wt = (T*)a.Wt[g];
@@ -740,7 +745,10 @@ int hyb_convert_weights(int dtype, int count, const float* const* W, void* const
         vec = vec && N[i] % 4 == 0 && K[i] % 4 == 0 && a.ldt[i] % 4 == 0 && ((uintptr_t)W[i] % 16 == 0) && ((uintptr_t)Wc[i] % 16 == 0) &&
               ((uintptr_t)Wt[i] % 16 == 0);
     if (vec) {
-        dim3 gridv(hyb_cdiv(maxK, 64), hyb_cdiv(maxN, 64), count);
+        int tiles = 0;
+        for (int i = 0; i < count; ++i) { a.tile_begin[i] = tiles; tiles += hyb_cdiv(N[i], 64) * hyb_cdiv(K[i], 64); }
+        a.tile_begin[count] = tiles; a.count = count;
+        dim3 gridv(tiles);
         if (dtype == HYB_F32) hipLaunchKernelGGL(convert_weights_vec_kernel<float>, gridv, dim3(256), 0, st, a);
         else if (dtype == HYB_BF16) hipLaunchKernelGGL(convert_weights_vec_kernel<bf16>, gridv, dim3(256), 0, st, a);
         else return HYB_E_ARG;
