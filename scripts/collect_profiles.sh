@@ -28,6 +28,12 @@ for C in 2 4 5; do
   rm -f $OUT/kt_c$C/kt_kernel_trace.csv
   echo "kernel trace config $C done"
 done
+for M in bf16 bf16x3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$M -o kt -- python3 $REPO/bench.py --dtype $M --steps 12 --warmup 3 --no-cpu-baseline --no-pipeline --no-fwd-bwd-only --no-roofline --no-extra-legs > $OUT/st_$M.json 2> $OUT/st_$M.err
+  python3 $REPO/scripts/step_trace.py $OUT/st_$M/kt_kernel_trace.csv > $OUT/step_trace_$M.txt
+  rm -f $OUT/st_$M/kt_kernel_trace.csv
+  echo "step trace $M done"
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_enc32k -o kt -- python3 $REPO/scripts/enc32k_bench.py --frames 16 --reps 5 > $OUT/enc32k_under_rocprof.json 2> $OUT/kt_enc32k.err || true
 rm -f $OUT/kt_enc32k/kt_kernel_trace.csv
 echo "kernel trace Encoder_32K done"

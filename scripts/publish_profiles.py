@@ -13,6 +13,9 @@ for name in ("default", "c2", "c2_eager", "c4", "c5", "fp32", "bf16x3"):
     cp(f"bench_{name}.json", f"{tag}_bench_{name}.json")
 for c in (2, 4, 5):
     cp(f"kt_c{c}/kt_kernel_stats.csv", f"{tag}_kernel_stats_c{c}.csv")
+for m in ("bf16", "bf16x3"):
+    cp(f"step_trace_{m}.txt", f"{tag}_step_trace_{m}.txt")
+cp("st_bf16x3/kt_kernel_stats.csv", f"{tag}_kernel_stats_c2_bf16x3.csv")
 cp("attention_microbench.json", f"{tag}_attention_microbench.json")
 cp("fct_bench.json", f"{tag}_fct_bench.json")
 cp("stage1_bench.json", f"{tag}_stage1_bench.json")
