@@ -12,6 +12,9 @@
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
+                        float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
+                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
 
 namespace {
 
@@ -160,6 +163,119 @@ struct DwArgs {
     // 2*ln_D floats each
     int tiles, nriders; const float* ln_part[2]; int ln_rows, ln_D; float* ln_dgamma[2]; float* ln_dbeta[2];
 };
+
+// bf16 form of the kernel below without the transposing LDS stores (they conflicted on 83 % of the cycles): the two operand tiles are
+// staged as they lie in memory -- [row m][64 columns], 16-byte loads and stores, ALL of up to 128 rows in one round (one memory latency
+// instead of four) -- and the fragments, whose K dimension is the row m, come from the transposing LDS read ds_read_b64_tr_b16.
+constexpr int DWT_ROWS = 128, DWT_STRIDE = 64 + 16;        // row stride 80 elements: conflict-free transposing reads (as conv_wgrad.hip)
+typedef __attribute__((address_space(3))) bf16x4 dwt_lds_q;
+__device__ __forceinline__ void dwt_frag(Frag<bf16>& f, const bf16* tile, int m0, int c0, int lane) {
+    // 8 K values (rows m0 + 4q + 0..3 and m0 + 16 + 4q + 0..3, q = lane >> 4) of column c0 + (lane & 15)
+    const int qq = (lane & 15) >> 2, pp = lane & 3, q = lane >> 4;
+    const bf16* a0 = tile + (m0 + 4 * q + qq) * DWT_STRIDE + c0 + 4 * pp;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((dwt_lds_q*)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((dwt_lds_q*)(a0 + 16 * DWT_STRIDE));
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+    f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+}
+__global__ __launch_bounds__(256) void gemm_dw_multi_tr_kernel(DwArgs args) {
+    __shared__ __attribute__((aligned(16))) bf16 As[DWT_ROWS * DWT_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16 Bs[DWT_ROWS * DWT_STRIDE];
+    if ((int)blockIdx.x >= args.tiles) {                   // rider: column c of the LayerNorm partial rows, fixed order, eight loads in flight
+        const int per = (2 * args.ln_D + 255) / 256;
+        const int rid = ((int)blockIdx.x - args.tiles) / per;
+        const int c = (((int)blockIdx.x - args.tiles) - rid * per) * 256 + (int)threadIdx.x;
+        if (c >= 2 * args.ln_D) return;
+        const float* col = args.ln_part[rid] + c;
+        const long long ld = 2LL * args.ln_D;
+        float s = 0.f;
+        int r = 0;
+        for (; r + 8 <= args.ln_rows; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = col[(long long)(r + j) * ld];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < args.ln_rows; ++r) s += col[(long long)r * ld];
+        if (c < args.ln_D) args.ln_dgamma[rid][c] = s; else args.ln_dbeta[rid][c - args.ln_D] = s;
+        return;
+    }
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < DW_MAX_GROUPS; ++i)
+        if (i < args.ngroups && (int)blockIdx.x >= args.g[i].tile_begin) gi = i;
+    const DwGroup grp = args.g[gi];
+    const int local = blockIdx.x - grp.tile_begin;
+    const int bx = local % grp.tiles_x, by = local / grp.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by * 64, n0 = bx * 64;                  // m0: rows of dW (columns of dy), n0: columns of dW (columns of x)
+    const int p = lane & 15, q = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const bf16* dy = (const bf16*)grp.dy;
+    const bf16* mk = (const bf16*)grp.mask;
+    const bf16* x = (const bf16*)grp.x;
+    const int seg = tid & 7, row_t = tid >> 3;             // thread: 8 columns seg*8.., rows row_t + 32 u
+    for (int r0 = 0; r0 < args.M; r0 += DWT_ROWS) {
+        if (r0 > 0) __syncthreads();
+        Vec8<bf16> va[4], vm[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + row_t + 32 * u;
+            const bool rok = r < args.M;
+            if (rok && m0 + seg * 8 < grp.N) {
+                va[u].load(dy + (long long)r * grp.lddy + m0 + seg * 8);
+                if (mk) vm[u].load(mk + (long long)r * grp.lddy + m0 + seg * 8);
+            } else { va[u].zero(); if (mk) vm[u].zero(); }
+            if (rok && n0 + seg * 8 < grp.K) vb[u].load(x + (long long)r * grp.ldx + n0 + seg * 8); else vb[u].zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (mk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (!((float)vm[u].v[j] > 0.f)) va[u].v[j] = (bf16)0.f;
+            }
+            va[u].store(As + (row_t + 32 * u) * DWT_STRIDE + seg * 8);
+            vb[u].store(Bs + (row_t + 32 * u) * DWT_STRIDE + seg * 8);
+        }
+        __syncthreads();
+        const int rows = args.M - r0 < DWT_ROWS ? args.M - r0 : DWT_ROWS;
+        if (grp.db && bx == 0 && tid < 64) {                // bias gradient: column sums of the (masked) dy tile, rows in ascending order
+            for (int r = 0; r < rows; ++r) csum += (float)As[r * DWT_STRIDE + tid];
+        }
+        for (int k0 = 0; k0 < rows; k0 += 32) {             // rows beyond M are zero: a ragged last step contributes nothing
+            Frag<bf16> a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dwt_frag(a[i], As, k0, wm * 32 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dwt_frag(b[j], Bs, k0, wn * 32 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+        }
+    }
+    if (grp.db && bx == 0 && tid < 64 && m0 + tid < grp.N) grp.db[m0 + tid] = csum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int no = n0 + wn * 32 + j * 16 + p;
+            if (no >= grp.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = m0 + wm * 32 + i * 16 + 4 * q + r;
+                if (mo < grp.N) grp.dW[(long long)mo * grp.K + no] = acc[i][j][r];
+            }
+        }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
@@ -606,7 +722,14 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         int rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
         if (rc) return rc;
     }
-    if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]; the bias gradient (column sums of dym) rides in the same launch
+    if (dW && sizeof(T) == 2 && N % 8 == 0 && K % 8 == 0) {
+        // bf16: the multi-matrix weight-gradient kernel with one matrix -- the model-level path computes the same gradient as one group of
+        // its encoder launch, and the two must agree bit for bit
+        const void* dy_[1] = {dym}; const void* x_[1] = {x}; float* dW_[1] = {dW}; float* db_[1] = {db};
+        const int N_[1] = {N}, K_[1] = {K}, lddy_[1] = {N}, ldx_[1] = {ldx};
+        int rc = hyb_linear_dw_multi(HYB_BF16, 1, dy_, nullptr, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 0, nullptr, 0, 0, nullptr, nullptr);
+        if (rc) return rc;
+    } else if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]; the bias gradient (column sums of dym) rides in the same launch
         GemmArgs a{};
         a.g[0] = GemmGroup{dym, x, dW, nullptr, nullptr, db};
         a.Mo = N; a.No = K; a.R = M; a.lda = N; a.ldb = ldx; a.ldc = K; a.relu = 0; a.accumulate = 0;
@@ -721,7 +844,13 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
         for (int r = 0; r < nriders; ++r) { a.ln_part[r] = ln_part[r]; a.ln_dgamma[r] = ln_dgamma[r]; a.ln_dbeta[r] = ln_dbeta[r]; }
         blocks += nriders * hyb_cdiv(2 * ln_D, 256);
     }
+    static const int tr_env = getenv("HYB_DW_TR") ? atoi(getenv("HYB_DW_TR")) : 1;      // (=0: A/B, the transposing-store form)
+    bool aligned = true;                                   // 16-byte rows and bases for the straight vector staging
+    for (int i = 0; i < groups; ++i)
+        aligned = aligned && lddy[i] % 8 == 0 && ldx[i] % 8 == 0 && ((uintptr_t)dy[i] % 16 == 0) && ((uintptr_t)x[i] % 16 == 0) &&
+                  (!mask || !mask[i] || (uintptr_t)mask[i] % 16 == 0);
     if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    else if (dtype == HYB_BF16 && tr_env && aligned) hipLaunchKernelGGL(gemm_dw_multi_tr_kernel, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, st, a);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
