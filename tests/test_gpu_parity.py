@@ -288,7 +288,9 @@ def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,S,D,Hid,L,H,use_mask", [(2, 16, 64, 128, 2, 4, False), (1, 7, 32, 40, 1, 2, True), (8, 16, 512, 2048, 2, 8, False),
-                                                    (2, 96, 64, 128, 2, 4, False), (2, 128, 128, 256, 1, 4, True)])          # T = 96, 128 tokens
+                                                    (2, 96, 64, 128, 2, 4, False), (2, 128, 128, 256, 1, 4, True),           # T = 96, 128 tokens
+                                                    # deeper stacks: the weight gradients go layer by layer (one launch each) instead of one launch for all
+                                                    (2, 16, 64, 128, 3, 4, False), (1, 8, 32, 64, 4, 2, True)])
 def test_transformer_encoder_matches_oracle(mode, B, S, D, Hid, L, H, use_mask):
     ftol, gtol = TOL[mode]
     torch.manual_seed(3)
@@ -419,6 +421,8 @@ def _model_pair(mode, **kw):
     dict(B=1, T=8, H=112, W=112, kw={}),                                     # BASELINE config 1 shape, config-2 model
     dict(B=2, T=4, H=64, W=64, kw=dict(cnn_channels=(32, 64), d_model=64, num_heads=4, num_layers=2, hidden_dim=128)),
     dict(B=2, T=3, H=32, W=48, kw=dict(cnn_channels=(8, 16, 24), d_model=32, num_heads=2, num_layers=1, hidden_dim=48, num_classes=5)),
+    # three encoder layers: per-layer weight-gradient launches + the token projection's own
+    dict(B=2, T=4, H=32, W=32, kw=dict(cnn_channels=(16, 32), d_model=32, num_heads=2, num_layers=3, hidden_dim=64)),
 ])
 def test_full_model_logits_loss_and_grads_match_oracle(mode, cfg):
     """north_star gate: forward logits within 1e-3 rel of the CPU reference (fp32 mode); eval-mode BN + no dropout
