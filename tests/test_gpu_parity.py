@@ -31,6 +31,13 @@ from oracle import hybrid_ref_bf16 as RB  # noqa: E402
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 BF16_FWD, BF16_GRAD = 2e-3, 2e-2          # one stage, against the bf16-rounded oracle
 TOL = {"fp32": (1e-4, 1e-3), "bf16": (BF16_FWD, BF16_GRAD)}
+# fp32 storage, split-bf16 products (1e-5 relative): forward at the exact-fp32 mode's gate against the fp32 oracle.  Gradients behind a ReLU are
+# a different matter: a pre-activation within 1e-5 of zero lands on the other side in this mode, and that unit's whole gradient contribution
+# appears or vanishes (one row of dq/dk/dv at 1-2 % of the tensor's maximum, measured) -- a valid gradient of a function 1e-5 away.  So
+# gradients are gated on the relative L2 error of the tensor, which a flipped unit moves by ~ sqrt(1 / active units x rows): 4e-3 measured on
+# dv of the [8,16,512] attention shape (one flip expected among its 65 K units), 8.5e-3 on the first conv of the config-1 model (ReLU and
+# arg-max decisions of four stages) -- gate 2e-2; everything without such a decision in front of it measures 1e-5 .. 1e-4.
+TOL["bf16x3"] = (1e-4, 2e-2)
 _WORST = {}                               # what the bf16 comparisons actually measured (printed at the end of the module's run)
 
 
@@ -55,10 +62,11 @@ def rel(got, want, floor=0.0, l2=False):
 
 
 def check(got, want, tol, what, mode="fp32", floor=0.0, kind=None):
-    r = rel(got, want, floor, l2=(mode == "bf16"))
+    l2 = mode == "bf16" or (mode == "bf16x3" and kind is not None and "bwd" in kind)
+    r = rel(got, want, floor, l2=l2)
     if mode == "bf16" and kind:
         _note(kind, what, r)
-    assert math.isfinite(r) and r <= tol, f"{what}: {'L2' if mode == 'bf16' else 'max'} rel err {r:.3e} > {tol:.1e}"
+    assert math.isfinite(r) and r <= tol, f"{what}: {'L2' if l2 else 'max'} rel err {r:.3e} > {tol:.1e}"
 
 
 def check_param_grads(hip, ref, tol, mode, kind=None):
@@ -70,7 +78,7 @@ def check_param_grads(hip, ref, tol, mode, kind=None):
 
 def as_oracle(ref, mode):
     """fp32 mode: the fp32 oracle module itself.  bf16 mode: its fp64 copy, to be driven through oracle/hybrid_ref_bf16.py."""
-    if mode == "fp32":
+    if mode != "bf16":
         return ref
     import copy
     return copy.deepcopy(ref).double()
@@ -241,7 +249,7 @@ def test_golden_g2_reference_two_stage_on_hip():
 # --------------------------------------------------------------------------------------------
 # attention / encoder
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("B,S,D,H,use_mask", [(2, 16, 64, 4, False), (1, 1, 16, 2, False), (3, 5, 24, 3, True), (2, 33, 128, 2, True),
                                               (8, 16, 512, 8, False), (2, 64, 768, 8, False), (2, 64, 256, 2, True),
                                               (683, 7, 24, 3, False), (300, 16, 64, 8, True),      # >= 2048 problems: four per workgroup (+ a ragged last one)
@@ -286,7 +294,7 @@ def test_multihead_attention_matches_oracle(mode, B, S, D, H, use_mask):
     check_param_grads(hip, orc, gtol, mode, kind="mha bwd")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("B,S,D,Hid,L,H,use_mask", [(2, 16, 64, 128, 2, 4, False), (1, 7, 32, 40, 1, 2, True), (8, 16, 512, 2048, 2, 8, False),
                                                     (2, 96, 64, 128, 2, 4, False), (2, 128, 128, 256, 1, 4, True),           # T = 96, 128 tokens
                                                     # deeper stacks: the weight gradients go layer by layer (one launch each) instead of one launch for all
@@ -416,7 +424,7 @@ def _model_pair(mode, **kw):
     return ref, hip.cuda()
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("cfg", [
     dict(B=1, T=8, H=112, W=112, kw={}),                                     # BASELINE config 1 shape, config-2 model
     dict(B=2, T=4, H=64, W=64, kw=dict(cnn_channels=(32, 64), d_model=64, num_heads=4, num_layers=2, hidden_dim=128)),
@@ -428,7 +436,7 @@ def test_full_model_logits_loss_and_grads_match_oracle(mode, cfg):
     """north_star gate: forward logits within 1e-3 rel of the CPU reference (fp32 mode); eval-mode BN + no dropout
     for the gradient check (SURVEY.md section 0.3 decision 4), then train-mode BN forward."""
     ftol, gtol = TOL[mode]
-    if mode == "fp32":
+    if mode != "bf16":
         ftol = 1e-3
     ref, hip = _model_pair(mode, **cfg["kw"])
     nc = cfg["kw"].get("num_classes", 8)
