@@ -1,6 +1,6 @@
 """The training step as replayed hipGraphs: zero_grad -> forward -> cross-entropy -> backward -> (gradient all-reduce) -> AdamW.
 
-Why: the step is ~90 small-to-medium kernel launches; issued eagerly they cost the host 1.4 ms of Python + launch time for ~1.6 ms
+Why: the step is ~70 small-to-medium kernel launches; issued eagerly they cost the host 1.4 ms of Python + launch time for ~1.6 ms
 of GPU work (scripts/host_jitter.py), so any kernel speed-up beyond ~15 % -- and any slower host, e.g. 8 ranks sharing one
 machine -- would leave the GPU waiting.  Captured once (torch.cuda.graphs = HIP stream capture) the step is one graph launch (three with data parallelism).
 
@@ -14,7 +14,7 @@ What makes capture legal here
   * step-dependent scalars live on the device: the kernels add a device counter to their by-value dropout seed, and AdamW forms
     its bias corrections from state['step'] + counter on the device (hyb_*'s seed_inc / step_inc arguments).  The counter is
     advanced inside the last graph, so every replay is a new step with new masks;
-  * BatchNorm running statistics are written by the captured multi-tensor copy of ops.commit_running_stats.
+  * BatchNorm running statistics are updated in place by the captured statistics kernels (hybrid::backbone_).
 
 Data parallelism (world > 1): the backward pass is captured in two pieces so that the gradient all-reduce of the temporal part
 (25 of the 27 MB) runs -- eagerly, on the collective's own stream, outside any graph, so any torch.distributed backend works --
