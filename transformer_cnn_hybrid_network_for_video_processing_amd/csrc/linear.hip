@@ -35,7 +35,7 @@ struct GemmArgs {
 
 constexpr int BK = 32, LDS_PAD = 8, LDS_ROW = BK + LDS_PAD;
 
-template <typename TS, typename T, bool TRANS, int ROWS>
+template <typename TS, typename T, bool TRANS, int ROWS, int LDT = LDS_ROW>
 __device__ __forceinline__ void stage_tile(const TS* __restrict__ src, const TS* __restrict__ mask, int ld, int row0, int nrows, int r0, int R,
                                            T* __restrict__ tile, int tid) {
     if (!TRANS) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void stage_tile(const TS* __restrict__ src, const TS*
             } else {
                 v.zero();
             }
-            v.store(tile + row * LDS_ROW + seg * 8);
+            v.store(tile + row * LDT + seg * 8);
         }
     } else {
         if (tid < ROWS * 4) {
@@ -77,18 +77,22 @@ __device__ __forceinline__ void stage_tile(const TS* __restrict__ src, const TS*
                 s.zero();
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tile[(seg * 8 + j) * LDS_ROW + r] = from_f32<T>(s.get(j));
+            for (int j = 0; j < 8; ++j) tile[(seg * 8 + j) * LDT + r] = from_f32<T>(s.get(j));
         }
     }
 }
 
-template <typename T, typename TA, typename TB, typename TC, bool TRANS_A, bool TRANS_B, int BM>
+// KS: 32-deep k-steps staged per round.  The 32 x 32-tile instantiations serve few-tile, latency-bound products (the token projection:
+// 32 workgroups); with KS = 4 a round has four times the loads in flight and a quarter of the barriers (15.4 -> 8 us for its dX product).
+// Same k order and MFMA grouping: bit-identical results.
+template <typename T, typename TA, typename TB, typename TC, bool TRANS_A, bool TRANS_B, int BM, int KS = 1>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
     constexpr int BN = BM;
     constexpr int WM = BM / 2, WN = BN / 2;            // per-wave sub-tile (2x2 waves)
     constexpr int MT = WM / 16, NTT = WN / 16;
-    __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LDS_ROW];
+    constexpr int LDR = KS * BK + LDS_PAD;             // LDS row stride (elements)
+    __shared__ __attribute__((aligned(16))) T As[BM * LDR];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LDR];
     const GemmGroup grp = args.g[blockIdx.z];
     const TA* A = (const TA*)grp.A;
     const TB* B = (const TB*)grp.B;
@@ -106,24 +110,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs args) {
         for (int j = 0; j < NTT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
 
-    for (int r0 = 0; r0 < args.R; r0 += BK) {
+    for (int r0 = 0; r0 < args.R; r0 += KS * BK) {
         __syncthreads();
-        stage_tile<TA, T, TRANS_A, BM>(A, (const TA*)grp.Amask, args.lda, m0, args.Mo, r0, args.R, As, tid);
-        stage_tile<TB, T, TRANS_B, BN>(B, (const TB*)nullptr, args.ldb, n0, args.No, r0, args.R, Bs, tid);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {                               // (sub-steps past R stage zeros: exact no-ops in the sums)
+            stage_tile<TA, T, TRANS_A, BM, LDR>(A, (const TA*)grp.Amask, args.lda, m0, args.Mo, r0 + ks * BK, args.R, As + ks * BK, tid);
+            stage_tile<TB, T, TRANS_B, BN, LDR>(B, (const TB*)nullptr, args.ldb, n0, args.No, r0 + ks * BK, args.R, Bs + ks * BK, tid);
+        }
         __syncthreads();
         if (grp.colsum && blockIdx.x == 0 && tid < BM) {            // bias gradient: row sums of the (masked) A tile
 #pragma unroll 8
-            for (int r = 0; r < BK; ++r) csum += to_f32<T>(As[tid * LDS_ROW + r]);
+            for (int r = 0; r < KS * BK; ++r) csum += to_f32<T>(As[tid * LDR + r]);
         }
-        Frag<T> a[MT], b[NTT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) frag_load(a[i], As + (wm * WM + i * 16 + p) * LDS_ROW + 8 * q);
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag<T> a[MT], b[NTT];
 #pragma unroll
-        for (int j = 0; j < NTT; ++j) frag_load(b[j], Bs + (wn * WN + j * 16 + p) * LDS_ROW + 8 * q);
+            for (int i = 0; i < MT; ++i) frag_load(a[i], As + (wm * WM + i * 16 + p) * LDR + ks * BK + 8 * q);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NTT; ++j) frag_load(b[j], Bs + (wn * WN + j * 16 + p) * LDR + ks * BK + 8 * q);
 #pragma unroll
-            for (int j = 0; j < NTT; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTT; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+        }
     }
     if (grp.colsum && blockIdx.x == 0 && tid < BM && m0 + tid < args.Mo) grp.colsum[m0 + tid] = csum;
 #pragma unroll
@@ -362,7 +372,9 @@ int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 64>), grid, dim3(256), 0, st, a);
     } else {
         dim3 grid(hyb_cdiv(a.No, 32), hyb_cdiv(a.Mo, 32), groups);
-        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 32>), grid, dim3(256), 0, st, a);
+        static const int ks4 = getenv("HYB_GEMM_KS4") ? atoi(getenv("HYB_GEMM_KS4")) : 1;       // (=0: A/B, one k-step per round)
+        if (ks4 && a.R >= 128) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 32, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TC, TRANS_A, TRANS_B, 32>), grid, dim3(256), 0, st, a);
     }
     HYB_LAUNCH_CHECK();
     return 0;
