@@ -114,3 +114,23 @@ def test_adamw_device_step_counter_advanced_by_the_launch_itself():
     two.set_step_counter(counter, advance=True)
     with pytest.raises(RuntimeError, match="one parameter group"):
         two.step()
+
+
+def test_adamw_more_tensors_than_one_launch_holds_with_an_advancing_counter():
+    """100 tensors = two launches of the 80-entry tensor table: both read the same step number, only the last one advances the counter."""
+    g = torch.Generator().manual_seed(7)
+    init = [torch.randn(int(n), generator=g).cuda() for n in torch.randint(1, 5000, (100,), generator=g)]
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    b = [torch.nn.Parameter(t.clone()) for t in init]
+    oa = torch.optim.AdamW(a, lr=1e-3)
+    ob = P.HybridAdamW(b, lr=1e-3)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ob.set_step_counter(counter, advance=True)
+    for step in range(3):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad = gr.clone(); pb.grad = gr.clone()
+        oa.step(); ob.step()
+        assert int(counter.item()) == step + 1
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pb.data, pa.data, rtol=2e-6, atol=2e-7)
