@@ -772,7 +772,7 @@ def main():
                                    f"CNN 32-64-128-256 + 2-layer transformer d={args.d_model} h={args.heads} hid={args.hidden}, 8 classes",
                        "global_batch": args.batch * world, "frames": args.frames,
                        "step": "zero_grad+fwd+cross_entropy+bwd+grad_allreduce+adamw",
-                       "launch": "3 replayed hipGraphs per step (graph.GraphedTrainStep)" if graphed else "eager (one Python-issued launch per kernel)" + (f"; graph capture fell back: {graph_fallback}" if graph_fallback else ""),
+                       "launch": (("1 replayed hipGraph per step" if world == 1 else "3 replayed hipGraphs per step, the gradient all-reduces between them") + " (graph.GraphedTrainStep)") if graphed else "eager (one Python-issued launch per kernel)" + (f"; graph capture fell back: {graph_fallback}" if graph_fallback else ""),
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",
