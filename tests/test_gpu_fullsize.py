@@ -2,14 +2,14 @@
 
 1. ORACLE PARITY AT FULL SIZE.  The CPU oracle costs ~0.3 s per clip-step on the GPU box's host cores, so a whole
    config-2 step is a few seconds: the HIP path is compared with oracle/hybrid_ref.py on the same seeded weights and clips
-   at [8,16,3,224,224] (config 2), [4,64,3,224,224] d=768 hid=3072 (config 4; BASELINE leaves B open, the bench uses 8) and
+   at [8,16,3,224,224] (config 2), [8,64,3,224,224] d=768 hid=3072 (config 4 at the bench's own batch: 512 frames, ~40 s of host work) and
    [4,16,3,448,448] (config 5), in train mode (BatchNorm batch statistics; attention dropout off so the run is deterministic,
    SURVEY.md section 0.3 decision 4): logits, loss, updated running statistics and EVERY parameter gradient.
      * fp32 mode is the gate: logits and loss within 1e-3 (north_star's tolerance; measured 6e-7); every gradient outside the conv
        stack within 1e-3 of the fp32 oracle; the conv-stack gradients (3-6 M summed products per element behind max-pool / ReLU
        routing, where the fp32 oracle is itself 1e-3..9e-3 away from its own fp64 run) within 5e-3 of the FP64 oracle;
      * bf16 mode is REPORTED against the fp32 oracle and against the bf16-rounded oracle (oracle/hybrid_ref_bf16.py) and gated
-       at 1.3 x the distances measured for this build (BF16_MEASURED below: logits 6.5e-3 .. 9.8e-3, gradients 5.5e-2 .. 6.3e-2 relative L2).  End to end the rounded oracle
+       at 1.3 x the distances measured for this build (BF16_MEASURED below: logits 6.5e-3 .. 1.06e-2, gradients 5.1e-2 .. 6.3e-2 relative L2).  End to end the rounded oracle
        cannot be tight -- rounding amplifies any summation-order difference to bf16 noise within a few stages (its docstring) --
        so the TIGHT bf16 gates (2e-3 forward, 2e-2 gradients) live in the per-stage tests of tests/test_gpu_parity.py.
 2. SIZE-INDEPENDENT PROPERTIES (kept from round 1): bit-identical repeat runs, clip independence (what makes batch-of-clips
@@ -26,7 +26,6 @@ pytestmark = pytest.mark.gpu
 CFG2 = dict(B=8, T=16, H=224, kw=dict())                                            # headline config
 CFG4 = dict(B=8, T=64, H=224, kw=dict(d_model=768, num_heads=8, hidden_dim=3072))   # long clip: T=64, d=768 (d_head 96)
 CFG5 = dict(B=4, T=16, H=448, kw=dict())                                            # high-res frames
-CFG4_ORACLE = dict(CFG4, B=4)                                                       # oracle parity: 256 frames of CPU work instead of 512
 
 
 def P():
@@ -172,7 +171,7 @@ def _l2rel(got, want, floor=0.0):
     return (got - want).norm().item() / max(want.norm().item(), floor * math.sqrt(want.numel()), 1e-30)
 
 
-ORACLE_CFGS = [("config2", CFG2), ("config4_B4_T64_d768", CFG4_ORACLE), ("config5_448", CFG5)]
+ORACLE_CFGS = [("config2", CFG2), ("config4_B8_T64_d768", CFG4), ("config5_448", CFG5)]
 
 
 @pytest.mark.parametrize("name,cfg", ORACLE_CFGS, ids=[n for n, _ in ORACLE_CFGS])
@@ -209,7 +208,7 @@ def test_fullsize_fp32_mode_matches_the_oracle(name, cfg):
 def test_fullsize_bf16x3_mode_meets_the_north_star_tolerance(name, cfg):
     """compute_dtype="bf16x3" -- fp32 storage, every contraction product from three bf16 MFMAs on two-term splits (hyb_common.h) -- is
     the fast mode that still meets north_star's 1e-3: logits and loss within 1e-3 of the fp32 oracle (measured ~1e-5), gradients
-    outside the conv stack within 1.7e-2 of the fp32 oracle (max-abs over the tensor's max; measured 2.8e-3 / 8.1e-3 / 1.27e-2 at configs
+    outside the conv stack within 1.7e-2 of the fp32 oracle (max-abs over the tensor's max; measured 2.8e-3 / 4.7e-3 / 1.27e-2 at configs
     2 / 4 / 5, the worst being the tiny key-projection gradients, where the softmax backward's dP - delta cancels; the FFN / projection
     weight gradients also sit behind ReLU decisions, and a pre-activation within 1e-5 of zero switches a whole hidden unit's
     contribution), conv-stack gradients within 1.2e-2 of the fp64 oracle (measured 8.1e-3 .. 8.8e-3) (ReLU and arg-max routing; the exact-fp32 mode is gated at 5e-3 there and the fp32 CPU oracle itself is up to
@@ -229,9 +228,9 @@ def test_fullsize_bf16x3_mode_meets_the_north_star_tolerance(name, cfg):
     assert e_log <= 1e-3
     assert abs(loss - f32["loss"]) <= 1e-3 * max(1.0, abs(f32["loss"]))
     for n in conv:
-        assert e_hip[n] <= 1.2e-2, (n, e_hip[n])          # measured 8.1e-3 / 8.6e-3 / 8.8e-3 (configs 2 / 4 / 5)
+        assert e_hip[n] <= 1.2e-2, (n, e_hip[n])          # measured 8.1e-3 / 8.7e-3 / 8.8e-3 (configs 2 / 4 / 5)
     for n in rest:
-        assert e_two[n] <= 1.7e-2, (n, e_two[n])          # measured 2.8e-3 / 8.1e-3 / 1.27e-2
+        assert e_two[n] <= 1.7e-2, (n, e_two[n])          # measured 2.8e-3 / 4.7e-3 / 1.27e-2
     for k, v in f32["running"].items():
         assert _maxrel(running[k], v) <= 1e-4, k
 
@@ -264,4 +263,4 @@ def test_fullsize_bf16_mode_against_both_oracles(name, cfg):
 
 
 # round 3, measured on MI355X (gpurun_out/r3_fullsize2.log; profiles/r03_bf16_error_table.txt)
-BF16_MEASURED = {"config2": (9.75e-3, 8.32e-3, 5.45e-2), "config4_B4_T64_d768": (8.73e-3, 5.47e-3, 5.93e-2), "config5_448": (6.53e-3, 4.48e-3, 6.25e-2)}
+BF16_MEASURED = {"config2": (9.75e-3, 8.32e-3, 5.45e-2), "config4_B8_T64_d768": (1.06e-2, 6.42e-3, 5.07e-2), "config5_448": (6.53e-3, 4.48e-3, 6.25e-2)}
