@@ -135,10 +135,14 @@ __global__ __launch_bounds__(256) void sliced_wgrad_kernel(const float* __restri
 // 16 consecutive features of 4 consecutive pixels per wave-load, fully coalesced.  A block owns NTL x KTL 16x16 output tiles of
 // one pixel slice, its 4 waves interleave over the slice's 4-pixel groups and are combined in a fixed order at the end.  The bias
 // gradient (column sums of dy) is one more MFMA per n tile against a constant ones operand.
-template <int NTL, int KTL>
+// IMPL: x is not the patch matrix but the NHWC image [n][H][W][Ci] (Ci % 16 == 0, so the 16 columns of a k tile are 16 channels of ONE tap);
+// row `pix` is the output pixel (n, ho, wo) of the convolution `g` and column (tap, ci) is gathered from input pixel (ho*stride - pad +
+// ky*dil, wo*stride - pad + kx*dil), zero outside the image: no patch matrix is written or read (a 3x3 conv's patch matrix is 9 x the
+// image; the taps of neighbouring pixels now meet in L2).
+template <int NTL, int KTL, bool IMPL>
 __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                            float* __restrict__ part, float* __restrict__ cpart /* [S][Nn] or null */, long long P,
-                                                           int Nn, int K, int kgroups, int slice_rows) {
+                                                           int Nn, int K, int kgroups, int slice_rows, ConvGeo g) {
     __shared__ __attribute__((aligned(16))) float red[NTL * KTL * 256 + NTL * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,6 +166,21 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
     }
     const float* dyp = dy + n0 + m;
     const float* xp = x + k0 + m;
+    // IMPL: per k tile the tap's input offset and channel; per lane the output pixel's coordinates, advanced by 16 pixels per iteration
+    int tdy[KTL], tdx[KTL], tci[KTL];
+    int wo = 0, ho = 0, nimg = 0;
+    if (IMPL) {
+#pragma unroll
+        for (int j = 0; j < KTL; ++j) {
+            const int kc = k0 + 16 * j, tap = kc / g.Ci;
+            tdy[j] = (tap / g.k) * g.dil - g.pad; tdx[j] = (tap % g.k) * g.dil - g.pad; tci[j] = kc - tap * g.Ci + m;
+            kok[j] = kok[j] && tap < g.k * g.k;
+        }
+        const long long pix0 = r_begin + 4 * wave + kq;
+        wo = (int)(pix0 % g.Wo);
+        const long long t = pix0 / g.Wo;
+        ho = (int)(t % g.Ho); nimg = (int)(t / g.Ho);
+    }
 #pragma unroll 2
     for (long long p0 = r_begin + 4 * wave; p0 < r_end; p0 += 16) {
         const long long pix = p0 + kq;
@@ -169,6 +188,18 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
         float a[NTL], b[KTL];
 #pragma unroll
         for (int i = 0; i < NTL; ++i) a[i] = (pok && nok[i]) ? dyp[pix * lddy + 16 * i] : 0.f;
+        if (IMPL) {
+            const int iy0 = ho * g.stride, ix0 = wo * g.stride;
+            const long long img = (long long)nimg * g.H;
+#pragma unroll
+            for (int j = 0; j < KTL; ++j) {
+                const int iy = iy0 + tdy[j], ix = ix0 + tdx[j];
+                const bool ok = pok && kok[j] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                b[j] = ok ? x[((img + iy) * g.W + ix) * g.Ci + tci[j]] : 0.f;
+            }
+            wo += 16;
+            while (wo >= g.Wo) { wo -= g.Wo; if (++ho == g.Ho) { ho = 0; ++nimg; } }
+        } else
 #pragma unroll
         for (int j = 0; j < KTL; ++j) b[j] = (pok && kok[j]) ? xp[pix * ldx + 16 * j] : 0.f;
 #pragma unroll
@@ -555,32 +586,35 @@ size_t hyb_sliced_wgrad_workspace(long long P, int Nn, int K) {
 }
 template <int NTL, int KTL>
 static void launch_direct_wgrad(const float* dy, int lddy, const float* x, int ldx, float* part, float* cpart, long long P, int Nn, int K, int S,
-                                int rows, hipStream_t st) {
+                                int rows, hipStream_t st, const ConvGeo* geo = nullptr) {
     const int kgroups = hyb_cdiv(K, 16 * KTL), ngroups = hyb_cdiv(Nn, 16 * NTL);
-    hipLaunchKernelGGL((direct_wgrad_kernel<NTL, KTL>), dim3(kgroups * ngroups, S), dim3(256), 0, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, kgroups,
-                       rows);
+    if (geo) hipLaunchKernelGGL((direct_wgrad_kernel<NTL, KTL, true>), dim3(kgroups * ngroups, S), dim3(256), 0, st, dy, lddy, x, ldx, part, cpart, P, Nn, K,
+                                kgroups, rows, *geo);
+    else hipLaunchKernelGGL((direct_wgrad_kernel<NTL, KTL, false>), dim3(kgroups * ngroups, S), dim3(256), 0, st, dy, lddy, x, ldx, part, cpart, P, Nn, K,
+                            kgroups, rows, ConvGeo{});
 }
 // out[Nn][K] (+)= dy^T x over P rows; colsum (optional, with its own partial workspace cws of hyb_sliced_colsum_workspace bytes):
 // colsum[Nn] (+)= column sums of dy, formed inside the same launch
+// geo != NULL: x is the NHWC image of the convolution `geo` (K = k*k*Ci, Ci % 16 == 0), gathered implicitly (direct_wgrad_kernel<.., true>)
 int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, float* out, float* colsum, long long P, int Nn, int K, int accumulate,
-                        void* ws, void* cws, hipStream_t st) {
+                        void* ws, void* cws, hipStream_t st, const ConvGeo* geo = nullptr) {
     static const int legacy = getenv("HYB_FCT_WGRAD_V1") ? atoi(getenv("HYB_FCT_WGRAD_V1")) : 0;      // first-generation kernel (A/B)
     int ntl, ktl, rows, S;
     direct_geometry(P, Nn, K, ntl, ktl, rows, S);
     float* cpart = colsum ? (float*)cws : nullptr;
-    if (legacy) {
+    if (legacy && !geo) {
         S = hyb_cdiv(P, SLICE_ROWS);
         const int tk = hyb_cdiv(K, 64), tn = hyb_cdiv(Nn, 64);
         hipLaunchKernelGGL(sliced_wgrad_kernel, dim3(tk * tn, S), dim3(256), 0, st, dy, lddy, x, ldx, (float*)ws, P, Nn, K, tk, SLICE_ROWS);
         if (colsum) hipLaunchKernelGGL(colsum_slice_kernel, dim3(S), dim3(256), 0, st, dy, lddy, cpart, P, Nn, SLICE_ROWS);
     } else if (ntl == 1) {
-        if (ktl == 2) launch_direct_wgrad<1, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
-        else if (ktl == 4) launch_direct_wgrad<1, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
-        else launch_direct_wgrad<1, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        if (ktl == 2) launch_direct_wgrad<1, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
+        else if (ktl == 4) launch_direct_wgrad<1, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
+        else launch_direct_wgrad<1, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
     } else {
-        if (ktl == 2) launch_direct_wgrad<2, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
-        else if (ktl == 4) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
-        else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st);
+        if (ktl == 2) launch_direct_wgrad<2, 2>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
+        else if (ktl == 4) launch_direct_wgrad<2, 4>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
+        else launch_direct_wgrad<2, 8>(dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, S, rows, st, geo);
     }
     {   // the slab sums of dW and (when wanted) of the bias gradient: one launch
         const int nb1 = hyb_cdiv((long long)Nn * K, 32), nb2 = colsum ? hyb_cdiv(Nn, 32) : 0;
@@ -648,6 +682,9 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
     // forward, no dcol matrix and no col2im pass
     static const int implicit_env = getenv("HYB_CONV_IMPLICIT") ? atoi(getenv("HYB_CONV_IMPLICIT")) : 1;
     const bool dgrad_implicit = implicit_env && dx && !ident && stride == 1 && dilation * (k - 1) >= pad && hyb_conv_implicit_ok(Co8, (long long)N * H * W);
+    // weight gradient straight from the image (no patch matrix) whenever a k tile of 16 columns stays inside one tap
+    static const int wgrad_implicit_env = getenv("HYB_WGRAD_IMPLICIT") ? atoi(getenv("HYB_WGRAD_IMPLICIT")) : 1;
+    const bool wgrad_implicit = wgrad_implicit_env && !ident && Ci % 16 == 0 && Kp == kk * Ci;
     // unpadded shapes need no repacking of the results: the slab sums land in dw (1x1: [Co][Ci] is the packed layout) and db directly
     float* dw_dst = (k == 1 && Kp == Ci && Co8 == Co) ? dw : dwp;
     float* db_dst = (Co8 == Co) ? db : dbp;
@@ -674,8 +711,12 @@ extern "C" int hyb_conv2d_bwd(const float* dy, const float* x, const float* w, c
             FCT_TRY(hyb_gemm_nt(HYB_F32, 1, A, B, Cc, nullptr, 0, (int)P, Kp, Co8, Co8, Co8, Kp, 0, 0, st));
             if (!ident) { launch_col2im(col, dx + off_in * Ci, Pin, g, st); HYB_LAUNCH_CHECK(); }
         }
-        if (!ident) { launch_im2col(x + off_in * Ci, col, P, g, st); HYB_LAUNCH_CHECK(); }
-        FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, ident ? x + off_in * Ci : col, Kp, dw_dst, db ? db_dst : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
+        if (wgrad_implicit) {
+            FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, x + off_in * Ci, Ci, dw_dst, db ? db_dst : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st, &g));
+        } else {
+            if (!ident) { launch_im2col(x + off_in * Ci, col, P, g, st); HYB_LAUNCH_CHECK(); }
+            FCT_TRY(hyb_sliced_wgrad_cs(dz, Co8, ident ? x + off_in * Ci : col, Kp, dw_dst, db ? db_dst : nullptr, P, Co8, Kp, chunk > 0, ws_w, ws_c, st));
+        }
     }
     if (dw_dst != dw) hipLaunchKernelGGL(conv_unpack_kernel, dim3(grid1((long long)Co * Ci * kk)), dim3(256), 0, st, (const float*)dwp, dw, Co, Ci, kk, Kp);
     if (db && db_dst != db) { hipError_t e = hipMemcpyAsync(db, dbp, (size_t)Co * 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
