@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < KTL; ++j) {
             const int kc = k0 + 16 * j, tap = kc / g.Ci;
-            tdy[j] = (tap / g.k) * g.dil - g.pad; tdx[j] = (tap % g.k) * g.dil - g.pad; tci[j] = kc - tap * g.Ci + m;
+            tdy[j] = (tap / g.k) * g.dil - g.pad; tdx[j] = (tap % g.k) * g.dil - g.pad;
+            tci[j] = (tdy[j] * g.W + tdx[j]) * g.Ci + kc - tap * g.Ci + m;       // element offset of (tap, channel) from the pixel's own position
             kok[j] = kok[j] && tap < g.k * g.k;
         }
         const long long pix0 = r_begin + 4 * wave + kq;
@@ -190,12 +191,11 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const float* __restri
         for (int i = 0; i < NTL; ++i) a[i] = (pok && nok[i]) ? dyp[pix * lddy + 16 * i] : 0.f;
         if (IMPL) {
             const int iy0 = ho * g.stride, ix0 = wo * g.stride;
-            const long long img = (long long)nimg * g.H;
+            const float* pb = x + (((long long)nimg * g.H + iy0) * g.W + ix0) * g.Ci;        // one 64-bit address per pixel, 32-bit offsets per tap
 #pragma unroll
             for (int j = 0; j < KTL; ++j) {
-                const int iy = iy0 + tdy[j], ix = ix0 + tdx[j];
-                const bool ok = pok && kok[j] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                b[j] = ok ? x[((img + iy) * g.W + ix) * g.Ci + tci[j]] : 0.f;
+                const bool ok = pok && kok[j] && (unsigned)(iy0 + tdy[j]) < (unsigned)g.H && (unsigned)(ix0 + tdx[j]) < (unsigned)g.W;
+                b[j] = ok ? pb[tci[j]] : 0.f;
             }
             wo += 16;
             while (wo >= g.Wo) { wo -= g.Wo; if (++ho == g.Ho) { ho = 0; ++nimg; } }
