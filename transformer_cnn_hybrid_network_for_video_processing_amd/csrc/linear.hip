@@ -15,6 +15,8 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
                         int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
+int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
+                         int accumulate, int transposed_b, hipStream_t st);
 
 namespace {
 
@@ -387,7 +389,11 @@ int launch_gemm(const GemmArgs& a, int groups, hipStream_t st) {
 // (operands are L2-resident: <= 4 MB), the 4 waves of a workgroup split K (wave w takes k-steps w, w+4, ...), and the
 // partial 32x32 tiles are combined through LDS once at the end.  Grid = (No/32, Mo/32, groups).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename TC, int NWV>
+// BMODE: where the B operand (the weights) comes from.  0: T [No][R], r-contiguous (the pre-converted copies of the encoder);
+//   1: the fp32 MASTER weights [No][R] (r-contiguous: two 16-byte loads + conversion per fragment);  2: fp32 master weights [R][No]
+//   (the transposed product dx = dy W: a lane's 8 r values are 8 rows, 16 lanes cover 64 contiguous bytes of each).  1 and 2 serve the
+//   Linear layers outside the encoder (frame-token projection), whose few-tile products took 9 / 14 us on the LDS-staged kernel.
+template <typename T, typename TC, int NWV, int BMODE = 0>
 __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args) {
     __shared__ float red[NWV][32][33];
     const GemmGroup grp = args.g[blockIdx.z];
@@ -402,6 +408,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
     const T* arow[2];
     const T* mrow[2];
     const T* brow[2];
+    int bcol[2];
+    const float* Bf = (const float*)grp.B;                 // BMODE 1, 2
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int r = m0 + i * 16 + p; if (r > args.Mo - 1) r = args.Mo - 1;
@@ -409,6 +417,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
         arow[i] = A + (long long)r * args.lda + 8 * q;
         mrow[i] = Mk ? Mk + (long long)r * args.lda + 8 * q : nullptr;
         brow[i] = B + (long long)c * args.ldb + 8 * q;
+        bcol[i] = c;
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -423,7 +432,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (ok) {
-                frag_load(a[i], arow[i] + k0); frag_load(b[i], brow[i] + k0);
+                frag_load(a[i], arow[i] + k0);
+                if (BMODE == 0) frag_load(b[i], brow[i] + k0);
+                else if (BMODE == 1) {
+                    const float* src = Bf + (long long)bcol[i] * args.ldb + k0 + 8 * q;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { b[i].v[j] = from_f32<T>(lo[j]); b[i].v[4 + j] = from_f32<T>(hi[j]); }
+                } else {
+                    const float* src = Bf + (long long)(k0 + 8 * q) * args.ldb + bcol[i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[i].v[j] = from_f32<T>(src[(long long)j * args.ldb]);
+                }
                 if (Mk) {
                     Frag<T> mk;
                     frag_load(mk, mrow[i] + k0);
@@ -702,6 +722,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 
 template <typename T>
 int linear_fwd_t(const void* x, int ldx, const float* W, const float* b, void* y, int M, int N, int K, int relu, hipStream_t st) {
+    if (sizeof(T) == 2) {                                   // few-tile products: eight waves split K, fragments straight from the master weights
+        const int rc = hyb_gemm_skinny_wf32(x, W, y, b, M, N, K, ldx, K, N, relu, 0, 0, st);
+        if (rc != -100) return rc;
+    }
     GemmArgs a{};
     a.g[0] = GemmGroup{x, W, y, b, nullptr, nullptr};
     a.Mo = M; a.No = N; a.R = K; a.lda = ldx; a.ldb = K; a.ldc = N; a.relu = relu; a.accumulate = 0;
@@ -728,11 +752,15 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         int rc = hyb_gemm_nt(sizeof(T) == 4 ? HYB_F32 : HYB_BF16, 1, A_, B_, C_, nullptr, 0, M, K, N, N, N, ldx, 0, accumulate_dx, st);
         if (rc) return rc;
     } else if (dx) { // dx[m][k] = sum_n dym[m][n] * W[n][k]
+        int rc = sizeof(T) == 2 ? hyb_gemm_skinny_wf32(dym, W, dx, nullptr, M, K, N, N, K, ldx, 0, accumulate_dx, 1, st) : -100;
+        if (rc != -100 && rc != 0) return rc;
+        if (rc == -100) {            // not a few-tile shape: the LDS-staged kernel
         GemmArgs a{};
         a.g[0] = GemmGroup{dym, W, dx, nullptr, nullptr, nullptr};
         a.Mo = M; a.No = K; a.R = N; a.lda = N; a.ldb = K; a.ldc = ldx; a.relu = 0; a.accumulate = accumulate_dx;
-        int rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
+        rc = launch_gemm<T, T, float, T, false, true>(a, 1, st);
         if (rc) return rc;
+        }
     }
     if (dW && sizeof(T) == 2 && N % 8 == 0 && K % 8 == 0) {
         // bf16: the multi-matrix weight-gradient kernel with one matrix -- the model-level path computes the same gradient as one group of
@@ -792,6 +820,23 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
     else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 4>), grid, dim3(256), 0, st, a);
     else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal: skinny product on the fp32 master weights (BMODE 1 / 2 of gemm_nt_splitk_kernel), bf16 activations; returns -100 when the
+// shape is not a few-tile one (the caller then takes the LDS-staged kernel)
+int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
+                         int accumulate, int transposed_b, hipStream_t st) {
+    static const int env = getenv("HYB_GEMM_WF32") ? atoi(getenv("HYB_GEMM_WF32")) : 1;
+    const dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), 1);
+    if (!env || (long long)grid.x * grid.y > 256 || R < 256 || R % 32 != 0 || lda % 8 != 0 || ((uintptr_t)A % 16) != 0) return -100;
+    if (!transposed_b && (ldb % 4 != 0 || ((uintptr_t)Bf % 16) != 0)) return -100;
+    GemmArgs a{};
+    a.g[0] = GemmGroup{A, Bf, C, bias, nullptr, nullptr};
+    a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
+    if (transposed_b) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8, 2>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8, 1>), grid, dim3(512), 0, st, a);
     HYB_LAUNCH_CHECK();
     return 0;
 }
