@@ -34,6 +34,8 @@ struct AttnDims {
     int ld_qkv;  // token row stride (elements) of q, k, v and dq, dk, dv (D, or 3D when they are packed as [M][3D])
     int ld_o;    // token row stride of out / dout
     int ppw;     // problems per workgroup: > 1 only for single-tile sequences (S <= 16), where every wave takes its own (clip, head)
+    int relu_out; // backward: dq, dk, dv are the gradients of ReLU outputs (the reference's projections end in a ReLU, src L69-70): zero them
+                  // where q, k, v are not positive, so that the consumers of the packed gradient need no mask operand
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -109,6 +111,21 @@ __device__ __forceinline__ void store4(T* dst, const f32x4& o) {
     } else {
         *reinterpret_cast<f32x4*>(dst) = o;
     }
+}
+
+// store4 behind a ReLU: zero where the forward value (same position in `ref`) is not positive
+template <typename T>
+__device__ __forceinline__ void store4_relu(T* dst, const T* ref, f32x4 o) {
+    if (sizeof(T) == 2) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(ref);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!((float)r[j] > 0.f)) o[j] = 0.f;
+    } else {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(ref);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(r[j] > 0.f)) o[j] = 0.f;
+    }
+    store4(dst, o);
 }
 
 constexpr int MAXT = 4;       // S <= 64
@@ -345,7 +362,10 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                         o = mma16(a, dsT[kt], o);
                     }
                 const int f0 = dt * 16 + 4 * g;
-                if (valid && qok && f0 < d.dh) store4(dq + ((long long)(b * d.S + query)) * d.ld_qkv + h * d.dh + f0, o);
+                if (valid && qok && f0 < d.dh) {
+                    const long long oq = ((long long)(b * d.S + query)) * d.ld_qkv + h * d.dh + f0;
+                    if (d.relu_out) store4_relu(dq + oq, q + oq, o); else store4(dq + oq, o);
+                }
             }
     }
     __syncthreads();                                           // delta of every query tile is in LDS
@@ -408,8 +428,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                         const int f0 = dt * 16 + 4 * g;
                         if (valid && kok && f0 < d.dh) {
                             const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
-                            store4(dk + o, tk);
-                            store4(dv + o, tv);
+                            if (d.relu_out) { store4_relu(dk + o, k + o, tk); store4_relu(dv + o, v + o, tv); }
+                            else { store4(dk + o, tk); store4(dv + o, tv); }
                         }
                     } else {
                         dkT[dt] = mma16(aq, dsF, dkT[dt]);
@@ -424,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                 const int f0 = dt * 16 + 4 * g;
                 if (valid && kok && f0 < d.dh) {
                     const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
-                    store4(dk + o, dkT[dt]);
-                    store4(dv + o, dvT[dt]);
+                    if (d.relu_out) { store4_relu(dk + o, k + o, dkT[dt]); store4_relu(dv + o, v + o, dvT[dt]); }
+                    else { store4(dk + o, dkT[dt]); store4(dv + o, dvT[dt]); }
                 }
             }
     }
@@ -443,6 +463,7 @@ inline bool attn_dims(AttnDims& d, int B, int S, int D, int H, size_t es) {
     d.ldi = bytes / (int)es;
     d.ld_qkv = D;
     d.ld_o = D;
+    d.relu_out = 0;
     // a grid of one-wave workgroups is dispatch-bound beyond a few thousand problems: pack four single-tile problems per workgroup then
     static const int ppw_env = getenv("HYB_ATTN_PPW") ? atoi(getenv("HYB_ATTN_PPW")) : 4;      // waves (= problems) per workgroup at S <= 16
     d.ppw = (d.nt == 1 && (long long)B * H >= 2048) ? (ppw_env >= 1 && ppw_env <= 16 ? ppw_env : 4) : 1;
@@ -526,11 +547,12 @@ int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void
     return HYB_E_ARG;
 }
 int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
-                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
+                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st, int relu_out) {
     AttnDims d;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     if (!qkv || !stats || !dout || !dqkv || !attn_dims(d, B, S, D, H, es)) return HYB_E_ARG;
     d.ld_qkv = 3 * D;
+    d.relu_out = relu_out;
     const char* base = (const char*)qkv;
     char* g = (char*)dqkv;
     if (dtype == HYB_F32) return attn_bwd_t<float>(base, base + D * es, base + 2 * D * es, mask, stats, dout, g, g + D * es, g + 2 * D * es, d, p_drop, seed, seed_inc, st);

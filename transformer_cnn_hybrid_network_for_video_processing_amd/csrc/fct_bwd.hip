@@ -14,7 +14,8 @@
 #include "conv_geo.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr,
+                const void* const* Cmask = nullptr);
 
 bool hyb_conv_implicit_ok(int Ci, long long rows);
 int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, float* y, int n_img, int H, int W, int Ci, int Ho, int Wo, int Co,

@@ -11,7 +11,8 @@
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr,
+                const void* const* Cmask = nullptr);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
                         int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
@@ -27,6 +28,8 @@ struct GemmGroup {
     const float* bias;
     const void* Amask;      // optional, same layout/type as A: A is used as A * (Amask > 0)  (ReLU backward fused into the loader)
     float* colsum;          // optional (dW kernel): colsum[mo] = sum_r A(mo, r)   (bias gradient fused into the weight-gradient GEMM)
+    const void* Cmask;      // optional (skinny kernel), same layout/type as C: the result is stored as C * (Cmask > 0) -- the ReLU backward of the
+                            // layer BELOW fused into this product's epilogue, so that its consumers need no mask operand
 };
 struct GemmArgs {
     GemmGroup g[3];
@@ -479,6 +482,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
         if (args.relu) v = fmaxf(v, 0.f);
         TC* dst = C + (long long)mo * args.ldc + no;
         if (args.accumulate) v += to_f32<TC>(*dst);
+        if (grp.Cmask && !(to_f32<TC>(((const TC*)grp.Cmask)[(long long)mo * args.ldc + no]) > 0.f)) v = 0.f;
         *dst = from_f32<TC>(v);
     }
 }
@@ -794,17 +798,20 @@ int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const v
 
 // Internal (same shared object): skinny NT GEMM on pre-converted T operands, up to 3 groups.
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask) {
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask,
+                const void* const* Cmask) {
     if (groups < 1 || groups > 3 || R % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return HYB_E_ARG;
+    if (Cmask && out_f32) return HYB_E_ARG;              // (the output mask has the storage type; it lives in the skinny kernel only)
     GemmArgs a{};
-    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr, Amask ? Amask[i] : nullptr, nullptr};
+    for (int i = 0; i < groups; ++i)
+        a.g[i] = GemmGroup{A[i], B[i], C[i], bias ? bias[i] : nullptr, Amask ? Amask[i] : nullptr, nullptr, Cmask ? Cmask[i] : nullptr};
     a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), groups);
     // few tiles (M = 128, N = 512: 64 workgroups on 256 CUs): eight waves split K to shorten the per-wave load/MFMA chain
     static const int w8env = getenv("HYB_GEMM_W8") ? atoi(getenv("HYB_GEMM_W8")) : 1;
     const bool w8 = w8env && (long long)grid.x * grid.y * grid.z <= 256 && R >= 256;
     static const int tall_env = getenv("HYB_GEMM_TALL") ? atoi(getenv("HYB_GEMM_TALL")) : 1;
-    if (dtype == HYB_F32 && tall_env && groups == 1 && !Amask && Mo >= 2048) {
+    if (dtype == HYB_F32 && tall_env && groups == 1 && !Amask && !Cmask && Mo >= 2048) {
         // pixel-side GEMMs (M = N*H*W): one pass over A per column tile, four independent waves per workgroup
         const int row_blocks = hyb_cdiv(Mo, 128);
         const int nt = No > 32 ? 4 : No > 16 ? 2 : 1;

@@ -7,7 +7,8 @@
 #include "hyb_common.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
-                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr);
+                int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr,
+                const void* const* Cmask = nullptr);
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
                         const int* ldt, hipStream_t st);
 int hyb_ln_bwd_rows(int M);
@@ -26,7 +27,7 @@ int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const vo
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
                              unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
 int hyb_attention_bwd_packed(int dtype, const void* qkv, const float* mask, const float* stats, const void* dout, void* dqkv, int B, int S, int D,
-                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st);
+                             int H, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st, int relu_out);
 extern "C" size_t hyb_attention_long_workspace(int dtype, int B, int S, int D, int H);
 int hyb_linear_bwd_wt(int dtype, const void* x, int ldx, const float* W, const void* Wt, const void* y, const void* dy, void* dx, int accumulate_dx,
                       float* dW, float* db, int M, int N, int K, int relu, void* ws, size_t ws_bytes, hipStream_t st);
@@ -353,11 +354,12 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), b.g1, g2, 0, b.lnpart, M, D,
                                          (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, st));
         // FFN second Linear: dX = g1 . W2 (pre-transposed copy)
-        { const void* A_[1] = {b.g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {b.dh};
-          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st)); }
-        // FFN first Linear (+ReLU): the mask (hmid > 0) is applied inside the GEMM loaders
-        { const void* A_[1] = {b.dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2}; const void* M_[1] = {base + lay.hmid};
-          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st, M_)); }
+        // (its epilogue applies the ReLU backward of the first Linear, dh *= (hmid > 0): the two products that read dh need no mask operand)
+        { const void* A_[1] = {b.g1}; const void* B_[1] = {base + lay.wt[5]}; void* C_[1] = {b.dh}; const void* CM_[1] = {base + lay.hmid};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, Hid, D, D, D, Hid, 0, 0, st, nullptr, CM_)); }
+        // FFN first Linear (+ReLU, applied above)
+        { const void* A_[1] = {b.dh}; const void* B_[1] = {base + lay.wt[4]}; void* C_[1] = {g2};
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, Hid, Hid, Hid, D, 0, 1, st)); }
         // LN1 + residual
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, g2, base + lay.o, P[12], (const float*)(base + lay.st1), b.g1b, gx, 0,
                                          b.lnpart + (size_t)lnrows * 2 * D, M, D, 1.0f, 0.f, 0ull, nullptr, st));
@@ -371,17 +373,19 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
                                            (char*)b.dqkv + 2 * (size_t)D * es, 3 * D, B, S, D, H, attn_p, attn_seed(seed, i), seed_inc,
                                            long_ws, lay.long_ws_bytes, st));
         else
+        // (short sequences: the attention backward zeroes d(q|k|v) where the projections' ReLU was off, so their consumers need no mask)
         HYB_TRY(hyb_attention_bwd_packed(dtype, base + lay.qkv, mask, (const float*)(base + lay.probs), g4, b.dqkv, B, S, D, H, attn_p,
-                                         attn_seed(seed, i), seed_inc, st));
+                                         attn_seed(seed, i), seed_inc, st, 1));
         // Q, K, V projections (+ReLU) share the layer input: one K-concatenated dX GEMM
         { const void* A_[1] = {b.dqkv}; const void* B_[1] = {base + lay.wt[0]}; void* C_[1] = {gx}; const void* M_[1] = {base + lay.qkv};
-          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, M_)); }
+          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, nullptr, 0, M, D, 3 * D, 3 * D, 3 * D, D, 0, 1, st, S > 64 ? M_ : nullptr)); }
         // the six weight (+ bias) gradients of the layer in ONE launch (768 tiles at config 2 instead of four 64-256-tile launches); the
         // layer's one LayerNorm is applied twice (quirk Q3): both calls' partial rows -> its weight/bias gradients ride in the same launch
         {
             const char* dq_ = (const char*)b.dqkv; const char* qk_ = base + lay.qkv;
             const void* dy_[6] = {b.g1, b.dh, b.g1b, dq_, dq_ + (size_t)D * es, dq_ + 2 * (size_t)D * es};
-            const void* mk_[6] = {nullptr, base + lay.hmid, nullptr, qk_, qk_ + (size_t)D * es, qk_ + 2 * (size_t)D * es};
+            const bool qm = S > 64;                        // (the long-sequence attention backward leaves d(q|k|v) unmasked)
+            const void* mk_[6] = {nullptr, nullptr, nullptr, qm ? qk_ : nullptr, qm ? qk_ + (size_t)D * es : nullptr, qm ? qk_ + 2 * (size_t)D * es : nullptr};
             const void* x_[6] = {base + lay.hmid, base + lay.x1, base + lay.attn, base + lay.x_in, base + lay.x_in, base + lay.x_in};
             float* dW_[6] = {G[10], G[8], G[6], G[0], G[2], G[4]};
             float* db_[6] = {G[11], G[9], G[7], G[1], G[3], G[5]};
