@@ -114,6 +114,8 @@ def test_encoder_ctor_contract():
     assert enc.attention_layers[0]._attn_p() == 0.0           # quirk Q5: attention dropout follows train()/eval()
     with pytest.raises(ValueError):
         P.TransformerCNNHybrid(compute_dtype="fp16")
+    with pytest.raises(ValueError, match="multiple of 8"):       # the token projection's 16-byte rows: said at construction, not as a C status later
+        P.TransformerCNNHybrid(cnn_channels=(8, 12))
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -153,6 +153,10 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
                  num_classes=8, dropout=0.0, compute_dtype="bf16"):
         super().__init__()
         chans = (in_channels,) + tuple(cnn_channels)
+        if chans[-1] % 8 != 0:
+            # the frame-token projection reads 16-byte rows of its [d_model, C] weight and of the pooled features
+            raise ValueError(f"TransformerCNNHybrid on the MI355X HIP path needs cnn_channels[-1] to be a multiple of 8 (got {chans[-1]}); "
+                             "there is no CPU fallback")
         self.num_stages = len(cnn_channels)
         for i in range(self.num_stages):
             setattr(self, f"encoder{i + 1}", ConvBNReLUPool(chans[i], chans[i + 1], f"enc{i + 1}", compute_dtype))
