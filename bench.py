@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_F32_PEAK_TFLOPS = 157.3
+# bf16x3: every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi), so the mode's own ceiling in useful FLOPs is a third of the bf16 peak
+MODE_PEAK = {"bf16": MFMA_BF16_PEAK_TFLOPS, "bf16x3": MFMA_BF16_PEAK_TFLOPS / 3.0, "fp32": MFMA_F32_PEAK_TFLOPS}
 HBM_PEAK_GBS = 8000.0               # HBM3E spec peak (6.29 TB/s measured copy)
 
 CFG = dict(cnn_channels=(32, 64, 128, 256), num_layers=2, num_classes=8)
@@ -208,17 +210,23 @@ def instep_kernel_table(args, step_fn, nsteps=8):
     chans = (3,) + CFG["cnn_channels"]
     specs = []
     H = args.size // 2
+    bf16 = getattr(args, "dtype", "bf16") == "bf16"
+    es = 2 if bf16 else 4                             # fp32 and bf16x3 store fp32 activations
     for li in range(1, 4):
         ci, co = chans[li], chans[li + 1]
         flops = 2.0 * 9 * ci * co * H * H * N
-        io = float(N * H * H * (ci + co) * 2)
-        specs.append((f"conv{li + 1}_fwd", 1, ci, co, "conv3x3_v2_kernel", flops, io))
-        specs.append((f"conv{li + 1}_dgrad", 1, co, ci, "conv3x3_v2_kernel", flops, io))
+        io = float(N * H * H * (ci + co) * es)
+        # kernel names as rocprofv3 lists them in this mode (fp32 / bf16x3: the float instances of the first-generation templates)
+        conv_name = "conv3x3_v2_kernel" if bf16 else "conv3x3_nhwc_kernel<float>"
+        specs.append((f"conv{li + 1}_fwd", 1, ci, co, conv_name, flops, io))
+        specs.append((f"conv{li + 1}_dgrad", 1, co, ci, conv_name, flops, io))
         # the wgrad kernel is fused with the BN/ReLU/pool backward: reads x, raw conv output y, dpooled; writes the dense gradient + dW
-        io_w = float(N * H * H * (ci + 2 * co) * 2 + N * (H // 2) * (H // 2) * co * 2)
-        # (kernel names as rocprofv3 lists them: the third-generation kernel takes 64-channel blocks on images of 28 k columns, conv_wgrad_v3.h)
+        io_w = float(N * H * H * (ci + 2 * co) * es + N * (H // 2) * (H // 2) * co * es)
+        # (the third-generation kernel takes 64-channel blocks on images of 28 k columns, conv_wgrad_v3.h)
         gen3 = ci % 64 == 0 and co % 64 == 0 and H % 28 == 0 and H % 4 == 0 and os.environ.get("HYB_WGRAD_V3", "1") != "0"
-        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, "wgrad_v3_kernel" if gen3 else "wgrad_v2_kernel<true, %d>" % (64 if ci % 64 == 0 else 32), flops, io_w))
+        wname = ("wgrad_v3_kernel" if gen3 else "wgrad_v2_kernel<true, %d>" % (64 if ci % 64 == 0 else 32)) if bf16 else \
+            "conv3x3_wgrad_kernel<float, %d, true>" % (4 if ci % 64 == 0 else 2)
+        specs.append((f"conv{li + 1}_wgrad", 2, ci, co, wname, flops, io_w))
         H //= 2
     evs = []
     for slot, sp in enumerate(specs):
@@ -267,6 +275,25 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def cpu_model_name():
+    """The host CPU as `lscpu` names it (the CPU baseline states the CPU model and the cores used)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    try:
+        out = subprocess.run(["lscpu"], stdout=subprocess.PIPE, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(args, budget_s=25.0):
     """The oracle (a port: stock torch fp32 on the host cores) on a bounded sample of the same workload: the configuration's own batch of
     clips, a warm-up step and up to four timed full steps inside the time budget (config 2: ~2.5 s per step on 16 cores, ~13 s in all)."""
@@ -295,7 +322,7 @@ def cpu_baseline(args, budget_s=25.0):
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=nb / med, unit="clips/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=nb / med, unit="clips/s", cores=torch.get_num_threads(), cpu=cpu_model_name(), kind="port",
                 sample=f"oracle/hybrid_ref.py fp32, {nb} clip{'s' if nb > 1 else ''} [{nb},{args.frames},3,{args.size},{args.size}] x {len(times)} full steps "
                        f"(median {med * 1e3:.0f} ms per step) after 1 warm-up")
 
@@ -364,6 +391,19 @@ def entry_point_roofline(totals, passes):
     return r
 
 
+def committed_traffic(kernel, cfgno, dtype):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 +
+    WRITE_SIZE, separate passes, per configuration and mode) -- (bytes, source) or (None, None)."""
+    for tname in ("r04_traffic.json",):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get(f"config{cfgno}_{dtype}", {}).get(kernel)
+            if t:
+                return t["hbm_bytes_per_launch"], (f"profiles/{tname} [config{cfgno}_{dtype}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                   f"`bench.py --config {cfgno} --dtype {dtype} --eager`; not re-measured in this run)")
+    return None, None
+
+
 def model_leg(cfgno, dtype, dev, steps, warmup, want_roofline):
     """A short run of one more configuration / precision mode: the same full step as the headline (graph replay when capture works)."""
     _import_torch()
@@ -408,13 +448,18 @@ def model_leg(cfgno, dtype, dev, steps, warmup, want_roofline):
            "graph_fallback": fallback is not None, "final_loss": float(loss.item())}
     if fallback:
         res["graph_fallback_reason"] = fallback
-    if want_roofline and dtype == "bf16":
+    if want_roofline:
         rows = instep_kernel_table(ns, fwd_bwd, nsteps=4)
         dom = dominant_kernel(rows)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        res["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms": dom["ms"], "flops_per_launch": dom["flops"],
+        traffic, tsrc = committed_traffic(dom["name"], cfgno, dtype)
+        res["roofline"] = {"kernel": dom["name"], "layers": dom["layers"], "bound": "mfma", "achieved": ach, "peak": MODE_PEAK[dtype], "unit": "TFLOP/s",
+                           "frac": ach / MODE_PEAK[dtype], "traffic": traffic, "traffic_source": tsrc, "ms": dom["ms"], "flops_per_launch": dom["flops"],
+                           "algorithmic_bytes_per_launch": dom["bytes"],
                            "how": "HIP events recorded by the library around this kernel inside 4 real steps (hyb_profile_set)"}
+        if dtype == "bf16x3":
+            res["roofline"]["peak_note"] = "2500 / 3 TFLOP/s: three bf16 MFMAs per product in this mode"
+        assert 0.0 < res["roofline"]["frac"] < 1.0, res["roofline"]       # (an events-timed-nothing hook once reported 83.6)
     if trainer is not None:
         trainer.close()
     ops.set_step_counter(None)
@@ -461,7 +506,7 @@ def fct_leg(dev, reps=5, frames=16, size=224):
     t0 = time.time()
     F.DiceLoss()(ref(xc), yc).backward()
     dt = time.time() - t0
-    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model_name(), "kind": "port",
                            "sample": f"oracle/fct_ref.py, one training pass on {n} frames [{n},3,{size},{size}] after 1 warm-up ({dt * 1e3:.0f} ms)"}
     del m, x, yt
     gc.collect(); torch.cuda.empty_cache()
@@ -505,7 +550,7 @@ def enc32k_leg(dev, reps=5, frames=16):
     t0 = time.time()
     E.forward(p, xc, True).square().mean().backward()
     dt = time.time() - t0
-    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    res["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model_name(), "kind": "port",
                            "sample": f"oracle/encoder32k_ref.py, one training pass on {n} frames after 1 warm-up ({dt * 1e3:.0f} ms)"}
     del m, x
     gc.collect(); torch.cuda.empty_cache()
@@ -790,10 +835,10 @@ def main():
         if not args.no_roofline and world == 1:
             rows = instep_kernel_table(args, trainer.eager_fwd_bwd if graphed else step)
             dom = dominant_kernel(rows)
-            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            peak = MODE_PEAK[args.dtype]
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic, tsrc = None, None
-            for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):           # PMC bytes per launch (rocprofv3 --pmc passes of this command)
+            traffic, tsrc = committed_traffic(dom["name"], args.config, args.dtype) if is_cfg else (None, None)
+            for tname in (() if traffic is not None else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):           # PMC bytes per launch (rocprofv3 --pmc passes of this command)
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and args.dtype == "bf16" and args.config == 2 and is_cfg:
                     t = json.load(open(tpath)).get(dom["name"])
@@ -825,7 +870,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             legs = (("config4", lambda: model_leg(4, "bf16", dev, 10, 3, True)), ("config5", lambda: model_leg(5, "bf16", dev, 10, 3, True)),
-                    ("fp32", lambda: model_leg(2, "fp32", dev, 10, 3, False)), ("bf16x3", lambda: model_leg(2, "bf16x3", dev, 10, 3, False)),
+                    ("fp32", lambda: model_leg(2, "fp32", dev, 10, 3, False)), ("bf16x3", lambda: model_leg(2, "bf16x3", dev, 10, 3, True)),
                     ("fct", lambda: fct_leg(dev)), ("enc32k", lambda: enc32k_leg(dev)), ("logits_check", lambda: bf16_logits_check(dev)),
                     ("cpu_baseline_config1", config1_cpu_baseline))
             for key, fn in legs:
@@ -835,6 +880,16 @@ def main():
                     out[key] = fn()
                 except Exception as e:                                      # noqa: BLE001 (a failed extra leg must not lose the headline)
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # the headline mode (bf16, BASELINE config 2's dtype) is at bf16 rounding level; north_star's "logits within 1e-3 rel of the CPU
+            # reference" is met by the bf16x3 mode: its throughput on the SAME workload, and the errors of both measured in this run
+            lc, x3 = out.get("logits_check", {}), out.get("bf16x3", {})
+            if "value" in x3 and "bf16x3" in lc:
+                out["value_at_north_star_tolerance"] = {
+                    "value": x3["value"], "unit": "clips/s", "dtype": "bf16x3", "ms_per_step": x3["ms_per_step"], "logits_rel_err": lc["bf16x3"],
+                    "tolerance": 1e-3, "headline_logits_rel_err": lc.get("bf16"),
+                    "what": "same config-2 full step in compute_dtype bf16x3 (fp32 storage, split-bf16 MFMA products): the fastest mode whose forward "
+                            "logits are within north_star's 1e-3 of the CPU oracle; the headline `value` is the bf16 mode, whose logits error is "
+                            "`headline_logits_rel_err`"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -415,11 +415,14 @@ int hyb_dropout2d(const float* x, float* y, int N, long long HW, int C, float p,
  * 1 - beta etc. are formed in double and rounded to fp32 once, like torch does.
  * step_inc: NULL, or a DEVICE pointer to one 64-bit counter: the step number used is step + *step_inc, read when the kernel runs
  * (the bias corrections are then formed on the device, in double) -- lets one captured launch serve every replay of a hipGraph.
- * advance != 0 (needs step_inc): the call also adds 1 to *step_inc once every workgroup has read it (the last workgroup to finish does
- * it), so the replayed step needs no separate "counter += 1" launch; one advancing call at a time per device. */
+ * advance_ticket != NULL (needs step_inc): the call also adds 1 to *step_inc once every workgroup has read it (the last workgroup to
+ * finish does it), so the replayed step needs no separate "counter += 1" launch.  advance_ticket is a DEVICE pointer to one 32-bit word
+ * owned by the caller, zero at rest, used by this counter's advancing launches only (the launch counts its finished workgroups there and
+ * leaves it zero): advancing calls on different counters -- two optimizers on two streams -- each bring their own word and never
+ * interfere; two advancing calls on the SAME counter must be stream-ordered, as any two steps of one optimizer are. */
 int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                    const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
-                   long long* step_inc, int advance, void* stream);
+                   long long* step_inc, unsigned int* advance_ticket, void* stream);
 
 #ifdef __cplusplus
 }

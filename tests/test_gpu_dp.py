@@ -86,6 +86,19 @@ def test_graph_and_eager_dp_steps_end_bit_equal():
     assert len(lines) == 2 and all("mismatching tensors []" in l and "all ranks equal True" in l for l in lines), lines
 
 
+def test_stock_ddp_wraps_the_hip_model():
+    """the drop-in module under torch's own DistributedDataParallel (two gloo ranks sharing cuda:0):
+    DDP's averaged gradients equal the hand-averaged local gradients and dp.GradAllReducer's, a stock AdamW step keeps the ranks equal
+    (tests/ddp_stock_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_stock_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("DDPW")]
+    assert r.returncode == 0, "\n".join(lines) + "\n" + r.stderr.decode()[-2000:]
+    assert len(lines) == 2 and all("ranks equal after AdamW True" in l and "state-dict keys True" in l for l in lines), lines
+
+
 _RCCL_SNIPPET = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)

@@ -206,24 +206,38 @@ def run_oracle(params, x, training, fn=R.feature_map):
     return p, y
 
 
-def compare_grads(model, p, worst_tol, median_tol):
-    """Whole-model gradients against the float64 oracle.  Two gates, because the comparison is limited by ReLU decisions, not by
-    arithmetic: an activation whose float64 value is within fp32 rounding of zero gets the other mask bit, and with a random-signed
-    upstream gradient one flipped element moves a sum over n elements by ~1/sqrt(n) of its size (the tail maps hold only 8-16 k
-    elements: 1-3 %).  torch's own fp32 CPU run of the oracle deviates from its float64 run by the same 3e-2 on the same tensors
-    (scripts/enc32k_debug.py), while every operator and the Bottleneck block match to 1e-4 / 1e-3 above.  So: the worst tensor must
-    stay within `worst_tol` and the median tensor within `median_tol`.  Gradients that are zero in exact arithmetic (the biases of
-    the tail convs: BatchNorm removes any constant) are measured against 1e-4 of the largest gradient."""
+def compare_grads(model, p, worst_tol, median_tol, arbiter=None):
+    """Whole-model gradients against the float64 oracle, with the oracle's own fp32 CPU run as the arbiter (as tests/test_gpu_fullsize.py
+    does for the hybrid).  The comparison is limited by ReLU decisions, not by arithmetic: an activation whose float64 value is within
+    fp32 rounding of zero gets the other mask bit, and with a random-signed upstream gradient one flipped element moves a sum over n
+    elements by ~1/sqrt(n) of its size (the tail maps hold only 8-16 k elements: 1-3 %).  Any correct fp32 implementation shows that
+    spread, so it is MEASURED here instead of allowed for: `arbiter` holds the same oracle run in fp32 on the CPU, and every tensor of the
+    HIP path must be within 2 x the arbiter's own distance from float64 (+ 2e-3: tensors on which the arbiter happens to flip nothing).
+    On top, the absolute gates: worst tensor `worst_tol`, median tensor `median_tol`.  Gradients that are zero in exact arithmetic (the
+    biases of the tail convs: BatchNorm removes any constant) are measured against 1e-4 of the largest gradient."""
     floor = 1e-4 * max(v.grad.abs().max().item() for v in p.values() if v.requires_grad and v.grad is not None)
-    errs = {}
+    errs, arb = {}, {}
     for name, prm in model.named_parameters():
         assert prm.grad is not None, name
         errs[name] = rel(prm.grad, p[name].grad, floor)
+        if arbiter is not None:
+            arb[name] = rel(arbiter[name].grad, p[name].grad, floor)
     worst = max(errs, key=errs.get)
     median = sorted(errs.values())[len(errs) // 2]
-    print(f"gradient errors: worst {errs[worst]:.2e} ({worst}), median {median:.2e}")
+    print(f"gradient errors: worst {errs[worst]:.2e} ({worst}), median {median:.2e}" +
+          (f"; fp32 CPU arbiter: worst {max(arb.values()):.2e}, median {sorted(arb.values())[len(arb) // 2]:.2e}" if arb else ""))
     assert errs[worst] < worst_tol, (worst, errs[worst])
     assert median < median_tol, median
+    for name in arb:
+        assert errs[name] <= 2.0 * arb[name] + 2e-3, (name, errs[name], arb[name])
+
+
+def run_arbiter(params, x, dy, training, fn=R.feature_map):
+    """The oracle's own graph in fp32 on the CPU, same inputs: how far ANY fp32 run lands from the float64 one."""
+    p32 = {k: (v.float().clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.float().clone() if v.is_floating_point() else v.clone())
+           for k, v in params.items()}
+    fn(p32, x.float(), training).backward(dy.float())
+    return p32
 
 
 @pytest.mark.parametrize("stride,widen", [(1, False), (1, True), (2, True)])
@@ -281,7 +295,7 @@ def test_encoder_64px_training_step_matches_oracle():
     assert tuple(got.shape) == (4, 8, 16, 16)
     assert rel(got, want) < 1e-3
     got.backward(dy.float().cuda())
-    compare_grads(model, p, 6e-2, 1e-2)
+    compare_grads(model, p, 4e-2, 5e-3, run_arbiter(params, x, dy, True))
     for name, buf in model.named_buffers():                          # running statistics moved like torch's
         if "running" in name:
             assert rel(buf, p[name]) < 1e-4, name
@@ -304,7 +318,7 @@ def test_encoder_256px_tokens_forward_backward_and_eval():
     assert tuple(got.shape) == (2, 8, 4096)                           # 8 tokens of 4096 features per frame
     assert rel(got, want) < 1e-3
     got.backward(dy.float().cuda())
-    compare_grads(model, p, 6e-2, 1e-2)
+    compare_grads(model, p, 4e-2, 5e-3, run_arbiter(params, x, dy, True, R.forward))
     model.eval()                                                      # running statistics normalise
     with torch.no_grad():
         got_e = model(x.float().cuda())
@@ -320,6 +334,11 @@ def test_encoder_train_mode_dropout_and_clip_folding():
     tokens = model(clips.flatten(0, 1))
     assert tuple(tokens.shape) == (3, 8, 4096)
     dead = (tokens.abs().amax(dim=2) == 0)
-    assert 0 < int(dead.sum()) < 24 or True                           # 24 planes at p = 0.3: usually some, never all
+    # 24 planes, each dropped with p = 0.3 by the library's counter-based RNG (deterministic under torch.manual_seed): Binomial(24, 0.3)
+    # has mean 7.2, sd 2.2; P(count outside [1, 16]) < 3e-4 -- and a seed that landed there would fail on every run, not flake
+    assert 1 <= int(dead.sum()) <= 16, int(dead.sum())
+    # over 40 independent draws (960 planes) the drop rate is pinned much tighter: 0.3 +- 4.5 sd = [0.233, 0.367]
+    drops = sum(int((model(clips.flatten(0, 1)).detach().abs().amax(dim=2) == 0).sum()) for _ in range(40))
+    assert 0.233 * 960 <= drops <= 0.367 * 960, drops
     tokens.square().mean().backward()
     assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in model.parameters())

@@ -134,3 +134,43 @@ def test_adamw_more_tensors_than_one_launch_holds_with_an_advancing_counter():
         assert int(counter.item()) == step + 1
         for pa, pb in zip(a, b):
             torch.testing.assert_close(pb.data, pa.data, rtol=2e-6, atol=2e-7)
+
+
+def test_two_advancing_optimizers_on_two_streams_do_not_share_a_ticket():
+    """the advancing launch used to count its finished workgroups in ONE process-global device word, so two advancing launches in
+    flight on one device (two models on two streams) could bump a counter early or never.  The ticket now belongs to the optimizer: two
+    optimizers, each with its own counter, stepping concurrently on two streams, must each count exactly their own steps and end with the
+    parameters of a host-stepped optimizer fed the same gradients."""
+    g = torch.Generator().manual_seed(11)
+    sizes = [300_000, 70_001, 4096, 1_000_003]                     # ~340 workgroups per launch: the two launches overlap on the device
+    init = [torch.randn(n, generator=g).cuda() for n in sizes]
+    K = 25
+    grads = [[torch.randn(n, generator=g).cuda() for n in sizes] for _ in range(3)]
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    oref = P.HybridAdamW(ref, lr=1e-3)
+    for k in range(K):
+        for p, gr in zip(ref, grads[k % 3]):
+            p.grad = gr
+        oref.step()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    models, opts, counters = [], [], []
+    for _ in range(2):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        o = P.HybridAdamW(ps, lr=1e-3)
+        c = torch.zeros(1, dtype=torch.int64, device="cuda")
+        o.set_step_counter(c, advance=True)
+        models.append(ps); opts.append(o); counters.append(c)
+    assert opts[0]._ticket.data_ptr() != opts[1]._ticket.data_ptr()
+    torch.cuda.synchronize()
+    for k in range(K):
+        for ps, o, st in zip(models, opts, streams):
+            with torch.cuda.stream(st):
+                for p, gr in zip(ps, grads[k % 3]):
+                    p.grad = gr
+                o.step()
+    torch.cuda.synchronize()
+    for ps, o, c in zip(models, opts, counters):
+        assert int(c.item()) == K
+        assert int(o._ticket.item()) == 0
+        for p, r in zip(ps, ref):
+            torch.testing.assert_close(p.data, r.data, rtol=1e-6, atol=1e-7)

@@ -26,6 +26,7 @@ _CTYPES = {
 
 
 DTYPE_FIRST = set()          # entry points whose first parameter is `int dtype`
+BOTH_BUILDS = ("hyb_profile_set", "hyb_profile_clear")      # no dtype argument, but state in each of the two libraries
 
 
 def parse_header(path=HEADER):
@@ -101,6 +102,8 @@ class _Mux(_Lib):
     def call(self, name, *args):
         if args and args[0] == HYB_F32X3 and name in DTYPE_FIRST and not isinstance(args[0], bool):
             return self.x3.call(name, HYB_F32, *args[1:])
+        if name in BOTH_BUILDS:            # process-global state that each build keeps for itself (the measurement hooks)
+            self.x3.call(name, *args)
         return super().call(name, *args)
 
     def query(self, name, *args):

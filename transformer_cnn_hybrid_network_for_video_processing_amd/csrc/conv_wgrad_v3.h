@@ -302,7 +302,12 @@ inline int w3_supported(int H, int W, int Cip, int Cop) {
 #ifdef HYB_NO_V3
     static const int v3 = 0;
 #else
-    static const int v3 = getenv("HYB_WGRAD_V3") ? atoi(getenv("HYB_WGRAD_V3")) : W3_DEFAULT;
+    static const int v3_env = getenv("HYB_WGRAD_V3") ? atoi(getenv("HYB_WGRAD_V3")) : W3_DEFAULT;
+#ifdef HYB_WGRAD_EXPERIMENTS
+    static const int v3 = v3_env;                       // 2 / 3: the experiment kernels of scripts/micro/wgrad_variants
+#else
+    static const int v3 = v3_env != 0;                  // the product build knows generations 0 and 1 only: any other value means "third"
+#endif
 #endif
     return (Cip % 64 == 0 && Cop % 64 == 0 && W % W3_TW == 0 && H % 4 == 0 && H >= 8) ? v3 : 0;
 }

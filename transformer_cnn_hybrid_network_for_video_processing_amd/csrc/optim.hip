@@ -21,6 +21,7 @@ struct AdamArgs {
     // from step + *step_inc
     const long long* step_inc;
     long long* advance;          // NULL, or = step_inc: the last workgroup to finish adds 1 to it (every workgroup has read it by then)
+    unsigned int* ticket;        // the caller's ticket word of THIS counter (zero at rest): workgroups finished in the running launch
     long long step;
     double lr, beta1d, beta2d;
 };
@@ -32,8 +33,6 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
     p -= step_size * (m / denom);
 }
-
-__device__ unsigned int adam_ticket = 0;           // workgroups finished in the running launch (reset by the last one)
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     __shared__ float s_corr[2];
@@ -71,8 +70,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     // workgroup has read" before the one write, which needs no fence (a release fence per workgroup costs an L2 write-back each: measured
     // 38 -> 126 us for this kernel).  The relaxed atomic is performed at the L2, in order per address.
     if (a.advance && threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(&adam_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(&adam_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *a.advance += 1;
         }
     }
@@ -82,8 +81,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 extern "C" int hyb_adamw_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                               const long long* numel, double lr, double beta1, double beta2, double eps, double weight_decay, long long step,
-                              long long* step_inc, int advance, void* stream) {
-    HYB_CHECK_ARG(count > 0 && params && grads && exp_avg && exp_avg_sq && numel && step >= 1 && lr >= 0.0 && (!advance || step_inc));
+                              long long* step_inc, unsigned int* advance_ticket, void* stream) {
+    HYB_CHECK_ARG(count > 0 && params && grads && exp_avg && exp_avg_sq && numel && step >= 1 && lr >= 0.0 && (!advance_ticket || step_inc));
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     for (int first = 0; first < count; first += ADAM_MAX) {
         AdamArgs a{};
@@ -103,7 +102,8 @@ extern "C" int hyb_adamw_step(int count, float* const* params, const float* cons
         a.step_size = (float)(lr / bc1);
         a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
         a.step_inc = step_inc; a.step = step; a.lr = lr; a.beta1d = beta1; a.beta2d = beta2;
-        a.advance = (advance && first + ADAM_MAX >= count) ? step_inc : nullptr;       // the last launch of the call advances the counter
+        a.advance = (advance_ticket && first + ADAM_MAX >= count) ? step_inc : nullptr;       // the last launch of the call advances the counter
+        a.ticket = advance_ticket;
         hipLaunchKernelGGL(adamw_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
         HYB_LAUNCH_CHECK();
     }

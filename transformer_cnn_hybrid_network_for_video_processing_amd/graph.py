@@ -94,7 +94,9 @@ class GraphedTrainStep:
             # tensors, and p.grad is re-bound to the set the last call wrote.
             self._grads_fb, self._loss_fb = [p.grad for p in params], self.loss
             self.gs = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gs, pool=self.ga.pool()):
+            # (its own memory pool: in A/B's pool the loss and gradient tensors step() returns could sit in blocks that A/B use as scratch,
+            # and a later fwd_bwd() would overwrite them -- ADVICE r3)
+            with torch.cuda.graph(self.gs):
                 self._piece_a(); self._piece_b(); self._piece_c()
             self._grads_step, self._loss_step = [p.grad for p in params], self.loss
             self._bound = "step"

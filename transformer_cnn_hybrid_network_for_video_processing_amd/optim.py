@@ -19,6 +19,7 @@ class HybridAdamW(torch.optim.Optimizer):
         self._tables = {}            # per group: cached pointer tables of the tensors whose addresses never change
         self._step_counter = None    # device int64 [1]: the kernel uses step + counter (captured launches, graph.GraphedTrainStep)
         self._advance = False
+        self._ticket = None          # device uint32 [1], this optimizer's own: the advancing launch counts its finished workgroups there
 
     def set_step_counter(self, counter, advance=False):
         """With a device counter the step number used by the kernel is state['step'] + counter, read on the device: one captured
@@ -27,6 +28,8 @@ class HybridAdamW(torch.optim.Optimizer):
         ONE group, so that one launch ends the step."""
         self._step_counter = counter
         self._advance = bool(advance) and counter is not None
+        if self._advance and (self._ticket is None or self._ticket.device != counter.device):
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=counter.device)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -87,5 +90,6 @@ class HybridAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             lib.call("hyb_adamw_step", len(ps), tab[2], ptr_array([g.data_ptr() for g in grads]), tab[3], tab[4], tab[5],
                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(),
-                     self._step_counter.data_ptr() if self._step_counter is not None else None, int(self._advance), _stream())
+                     self._step_counter.data_ptr() if self._step_counter is not None else None,
+                     self._ticket.data_ptr() if self._advance else None, _stream())
         return loss
