@@ -303,6 +303,25 @@ int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, cons
                      int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
                      const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* hyb_temporal_ce_*: hyb_temporal_* with the mean cross-entropy loss (the composite's own loss, the harness line `loss = criterion(model(x), y)`,
+ *   Model.py:56-57 / FCT.py:330-331) inside the same launches: the forward's last launch is LayerNorm + head + loss, the backward's first is
+ *   loss backward + head backward + LayerNorm backward -- every dependent launch costs >= 4.6 us on this chip, and these were 8 x 512 x 8
+ *   numbers in four launches each way.  target [B] class indices; loss [1]; dloss [1] = d(objective)/d(loss).
+ *   ce_scratch: B + 1 floats owned by the caller, ZERO before the first call and left zero-ticketed by every call (per-clip loss terms and
+ *   the ticket word the last workgroup resets); calls that share it must be stream-ordered.  Results equal hyb_temporal_* followed by
+ *   hyb_cross_entropy_* bit for bit. */
+int hyb_temporal_ce_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                        const float* head_w, const float* head_b, const float* mask, const long long* target, void* feat, void* tok,
+                        void* enc_saved, void* enc_out, float* logits, float* loss, float* ce_scratch, int B, int S, int HW, int C, int Cp,
+                        int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
+                        const unsigned long long* seed_inc, void* stream);
+int hyb_temporal_ce_bwd(int dtype, const float* dloss, const float* logits, const long long* target, const float* token_w,
+                        const float* const* enc_params, const float* head_w, const float* mask, const void* feat, const void* enc_saved,
+                        const void* enc_out, float* dtoken_w, float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b,
+                        void* dh, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes, float attn_p,
+                        float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* ---- FCT, the reference's "Fully Convolutional Transformer" (FCT.py:24-254; SURVEY.md section 8f-1, first "next" row) -----------
  * FORWARD entry points (the backward is the next step of this row).  Arrays are NHWC fp32 with the TRUE channel count
  * ([N,H,W,C]; a pixel's channels are contiguous: the token view of the spatial attention, FCT.py:69-74, is free).  Arithmetic is

@@ -211,8 +211,9 @@ def compare_grads(model, p, worst_tol, median_tol, arbiter=None):
     does for the hybrid).  The comparison is limited by ReLU decisions, not by arithmetic: an activation whose float64 value is within
     fp32 rounding of zero gets the other mask bit, and with a random-signed upstream gradient one flipped element moves a sum over n
     elements by ~1/sqrt(n) of its size (the tail maps hold only 8-16 k elements: 1-3 %).  Any correct fp32 implementation shows that
-    spread, so it is MEASURED here instead of allowed for: `arbiter` holds the same oracle run in fp32 on the CPU, and every tensor of the
-    HIP path must be within 2 x the arbiter's own distance from float64 (+ 2e-3: tensors on which the arbiter happens to flip nothing).
+    spread, so it is MEASURED here instead of allowed for: `arbiter` holds the same oracle run in fp32 on the CPU.  Which elements flip is
+    a coin toss per implementation, so the gate compares the two runs' error DISTRIBUTIONS, not tensor by tensor: the HIP path's worst tensor
+    must be within 2 x the arbiter's worst (+ 2e-3) and its median tensor within 2 x the arbiter's median (+ 1e-3).
     On top, the absolute gates: worst tensor `worst_tol`, median tensor `median_tol`.  Gradients that are zero in exact arithmetic (the
     biases of the tail convs: BatchNorm removes any constant) are measured against 1e-4 of the largest gradient."""
     floor = 1e-4 * max(v.grad.abs().max().item() for v in p.values() if v.requires_grad and v.grad is not None)
@@ -228,8 +229,10 @@ def compare_grads(model, p, worst_tol, median_tol, arbiter=None):
           (f"; fp32 CPU arbiter: worst {max(arb.values()):.2e}, median {sorted(arb.values())[len(arb) // 2]:.2e}" if arb else ""))
     assert errs[worst] < worst_tol, (worst, errs[worst])
     assert median < median_tol, median
-    for name in arb:
-        assert errs[name] <= 2.0 * arb[name] + 2e-3, (name, errs[name], arb[name])
+    if arb:
+        arb_worst, arb_median = max(arb.values()), sorted(arb.values())[len(arb) // 2]
+        assert errs[worst] <= 2.0 * arb_worst + 2e-3, (worst, errs[worst], arb_worst)
+        assert median <= 2.0 * arb_median + 1e-3, (median, arb_median)
 
 
 def run_arbiter(params, x, dy, training, fn=R.feature_map):

@@ -493,7 +493,7 @@ extern "C" int hyb_profile_clear(void) {
     return 0;
 }
 
-extern "C" int hyb_abi_version(void) { return 7; }
+extern "C" int hyb_abi_version(void) { return 8; }
 extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
 extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }
 

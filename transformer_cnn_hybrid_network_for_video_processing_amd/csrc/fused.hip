@@ -4,13 +4,28 @@
 //   hyb_backbone_{fwd,bwd} : `stages` x [Conv3x3 -> BatchNorm2d -> ReLU -> MaxPool2d]   (UNet.py:58-60 + UNet.py:13, UNet.py:32-37 order)
 //   hyb_temporal_{fwd,bwd} : global-average-pool + Linear frame token (composite's own) -> TransformerEncoder.forward
 //                            (TransformerEncoder.pyc src L110-126) -> mean over T + Linear head (composite's own)
+#include <stdlib.h>
 #include "hyb_common.h"
 
 size_t hyb_encoder_xin_offset(int dtype, int B, int S, int D, int Hid, int H);
 int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                          const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                          unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
-                         const HybDwExtra* extra);
+                         const HybDwExtra* extra, int tail_done, const HybDwRider* extra_rider);
+int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
+                         int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream,
+                         HybEncTail* tail);
+HybEncBwdTail hyb_encoder_bwd_tail(int dtype, const float* const* params, const void* saved, void* workspace, int B, int S, int D, int Hid, int L, int H,
+                                   float layer_p, unsigned long long seed);
+int hyb_ln_bwd_rows(int M);
+int hyb_temporal_tail_ok(int B, int S, int D, int C, int ln_rows);
+int hyb_temporal_tail_fwd(int dtype, const void* f, const void* x1, const float* gamma, const float* beta, void* enc_out, float* stats, int B, int S,
+                          int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, const float* W,
+                          const float* bias, float* logits, int C, const long long* target, float* loss, float* ce_scratch, hipStream_t st);
+int hyb_temporal_tail_bwd(int dtype, const float* dlogits, const float* logits, const long long* target, const float* dloss, const float* W,
+                          const void* enc_out, const void* f, const float* gamma, const float* stats, void* dx, void* dskip, float* ln_part,
+                          int ln_rows, float* head_part, int B, int S, int D, int C, float out_scale, float p_drop, unsigned long long seed,
+                          const unsigned long long* seed_inc, hipStream_t st);
 int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* weight, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, long long* nbt, int training, float momentum, float eps,
                            int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
@@ -141,17 +156,29 @@ extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// (the head's per-clip weight / bias gradient rows of the fused tail, [B][C*D + C] floats, are sized for the largest class count the head takes: 64)
+static size_t head_part_bytes(int B, int D) { return al256((size_t)B * ((size_t)64 * D + 64) * sizeof(float)); }
+
 extern "C" size_t hyb_temporal_bwd_workspace(int dtype, int B, int S, int HW, int Cp, int D, int Hid, int L, int H) {
     if (B <= 0 || S <= 0 || D <= 0) return 0;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const size_t M = (size_t)B * S;
-    return al256(hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) + 2 * al256(M * D * es) + al256(M * Cp * es);
+    return al256(hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) + 2 * al256(M * D * es) + al256(M * Cp * es) + head_part_bytes(B, D);
 }
 
-extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
-                                const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
-                                void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
-                                float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream) {
+// The tail of the temporal part runs as ONE launch each way when the shapes allow (hyb_temporal_tail_ok): forward = the last layer's second
+// LayerNorm + head (+ cross-entropy when a target is given), backward = (cross-entropy backward +) head backward + that LayerNorm's
+// backward.  HYB_TEMPORAL_TAIL=0: the separate launches (A/B; same results up to the order of two fixed-order sums).
+static int tail_enabled() {
+    static const int env = getenv("HYB_TEMPORAL_TAIL") ? atoi(getenv("HYB_TEMPORAL_TAIL")) : 1;
+    return env;
+}
+
+static int temporal_fwd_impl(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                             const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
+                             void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
+                             float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, const long long* target,
+                             float* loss, float* ce_scratch, void* stream) {
     HYB_CHECK_ARG(h && token_w && enc_params && head_w && feat && tok && enc_saved && enc_out && logits && B > 0 && S > 0 && HW > 0);
     const int N = B * S;
     HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
@@ -159,17 +186,42 @@ extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, 
     void* tok_dst = (char*)enc_saved + hyb_encoder_xin_offset(dtype, B, S, D, Hid, H);
     (void)tok;
     HYB_TRY(hyb_linear_fwd(dtype, feat, Cp, token_w, token_b, tok_dst, N, D, C, 0, stream));
-    HYB_TRY(hyb_encoder_fwd(dtype, tok_dst, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream));
+    const bool tail = tail_enabled() && hyb_temporal_tail_ok(B, S, D, classes, hyb_ln_bwd_rows(N));
+    HybEncTail t{};
+    HYB_TRY(hyb_encoder_fwd_impl(dtype, tok_dst, mask, enc_params, enc_out, enc_saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream,
+                                 tail ? &t : nullptr));
+    if (tail)
+        return hyb_temporal_tail_fwd(dtype, t.f, t.x1, t.gamma, t.beta, enc_out, t.st2, B, S, D, t.eps, t.out_scale, t.p_drop, t.seed, seed_inc, head_w,
+                                     head_b, logits, classes, target, loss, ce_scratch, (hipStream_t)stream);
     HYB_TRY(hyb_head_fwd(dtype, enc_out, head_w, head_b, logits, B, S, D, classes, stream));
+    if (target) HYB_TRY(hyb_cross_entropy_fwd(logits, target, loss, B, classes, stream));
     return 0;
 }
 
-extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, const float* const* enc_params, const float* head_w,
-                                const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
-                                float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
-                                int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
-                                const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
-    HYB_CHECK_ARG(dlogits && token_w && enc_params && head_w && feat && enc_saved && enc_out && dtoken_w && enc_grads && dhead_w && dh && workspace);
+extern "C" int hyb_temporal_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                                const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
+                                void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
+                                float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream) {
+    return temporal_fwd_impl(dtype, h, token_w, token_b, enc_params, head_w, head_b, mask, feat, tok, enc_saved, enc_out, logits, B, S, HW, C, Cp, D,
+                             Hid, L, H, classes, attn_p, layer_p, seed, seed_inc, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int hyb_temporal_ce_fwd(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
+                                   const float* head_w, const float* head_b, const float* mask, const long long* target, void* feat, void* tok,
+                                   void* enc_saved, void* enc_out, float* logits, float* loss, float* ce_scratch, int B, int S, int HW, int C, int Cp,
+                                   int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
+                                   const unsigned long long* seed_inc, void* stream) {
+    HYB_CHECK_ARG(target && loss && ce_scratch);
+    return temporal_fwd_impl(dtype, h, token_w, token_b, enc_params, head_w, head_b, mask, feat, tok, enc_saved, enc_out, logits, B, S, HW, C, Cp, D,
+                             Hid, L, H, classes, attn_p, layer_p, seed, seed_inc, target, loss, ce_scratch, stream);
+}
+
+static int temporal_bwd_impl(int dtype, const float* dlogits, const float* logits, const long long* target, const float* dloss, const float* token_w,
+                             const float* const* enc_params, const float* head_w, const float* mask, const void* feat, const void* enc_saved,
+                             const void* enc_out, float* dtoken_w, float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh,
+                             int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p,
+                             unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG((dlogits || (logits && target && dloss)) && token_w && enc_params && head_w && feat && enc_saved && enc_out && dtoken_w && enc_grads &&
+                  dhead_w && dh && workspace);
     if (workspace_bytes < hyb_temporal_bwd_workspace(dtype, B, S, HW, Cp, D, Hid, L, H)) return HYB_E_WORKSPACE;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const int N = B * S;
@@ -178,15 +230,55 @@ extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* to
     void* denc = ws + enc_ws;                                   // d(encoder output)
     void* dtok = ws + enc_ws + al256((size_t)N * D * es);       // d(tokens)
     void* dfeat = ws + enc_ws + 2 * al256((size_t)N * D * es);  // d(frame features), padded channels zero
-    HYB_TRY(hyb_head_bwd(dtype, enc_out, head_w, dlogits, denc, dhead_w, dhead_b, B, S, D, classes, stream));
+    float* head_part = (float*)(ws + enc_ws + 2 * al256((size_t)N * D * es) + al256((size_t)N * Cp * es));
     // the token projection's weight gradient (dtok^T feat) rides in the encoder backward's final multi-matrix launch
     const bool ride = C % 8 == 0;
     const HybDwExtra tokdw{dtok, feat, dtoken_w, dtoken_b, D, C, D, Cp};
-    HYB_TRY(hyb_encoder_bwd_impl(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws,
-                                 enc_ws, stream, ride ? &tokdw : nullptr));
+    const bool tail = tail_enabled() && dhead_b && hyb_temporal_tail_ok(B, S, D, classes, hyb_ln_bwd_rows(N)) && (ride || L <= 2);
+    if (tail) {
+        const HybEncBwdTail t = hyb_encoder_bwd_tail(dtype, enc_params, enc_saved, ws, B, S, D, Hid, L, H, layer_p, seed);
+        HYB_TRY(hyb_temporal_tail_bwd(dtype, dlogits, logits, target, dloss, head_w, enc_out, t.f, t.gamma, t.stats, t.dx, t.dskip, t.ln_part, t.ln_rows,
+                                      head_part, B, S, D, classes, t.out_scale, t.p_drop, t.seed, seed_inc, (hipStream_t)stream));
+        const long long cd = (long long)classes * D;
+        const HybDwRider hr{head_part, dhead_w, dhead_b, B, cd + classes, cd};
+        HYB_TRY(hyb_encoder_bwd_impl(dtype, nullptr, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws,
+                                     enc_ws, stream, ride ? &tokdw : nullptr, 1, &hr));
+    } else {
+        const float* dl = dlogits;
+        if (!dl) {      // cross-entropy backward as its own launch, into the head of the (not yet used) dfeat scratch
+            HYB_CHECK_ARG((size_t)B * classes * sizeof(float) <= al256((size_t)N * Cp * es));
+            HYB_TRY(hyb_cross_entropy_bwd(logits, target, dloss, (float*)dfeat, B, classes, stream));
+            dl = (const float*)dfeat;
+        }
+        HYB_TRY(hyb_head_bwd(dtype, enc_out, head_w, dl, denc, dhead_w, dhead_b, B, S, D, classes, stream));
+        HYB_TRY(hyb_encoder_bwd_impl(dtype, denc, mask, enc_params, enc_grads, enc_saved, dtok, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, ws,
+                                     enc_ws, stream, ride ? &tokdw : nullptr, 0, nullptr));
+    }
     if (Cp > C) { hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)N * Cp * es, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, ride ? nullptr : dtoken_w, ride ? nullptr : dtoken_b, N, D, C, 0, nullptr, 0,
                            stream));
     HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));
     return 0;
+}
+
+extern "C" int hyb_temporal_bwd(int dtype, const float* dlogits, const float* token_w, const float* const* enc_params, const float* head_w,
+                                const float* mask, const void* feat, const void* enc_saved, const void* enc_out, float* dtoken_w,
+                                float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b, void* dh, int B, int S, int HW, int C,
+                                int Cp, int D, int Hid, int L, int H, int classes, float attn_p, float layer_p, unsigned long long seed,
+                                const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
+    HYB_CHECK_ARG(dlogits);
+    return temporal_bwd_impl(dtype, dlogits, nullptr, nullptr, nullptr, token_w, enc_params, head_w, mask, feat, enc_saved, enc_out, dtoken_w, dtoken_b,
+                             enc_grads, dhead_w, dhead_b, dh, B, S, HW, C, Cp, D, Hid, L, H, classes, attn_p, layer_p, seed, seed_inc, workspace,
+                             workspace_bytes, stream);
+}
+extern "C" int hyb_temporal_ce_bwd(int dtype, const float* dloss, const float* logits, const long long* target, const float* token_w,
+                                   const float* const* enc_params, const float* head_w, const float* mask, const void* feat, const void* enc_saved,
+                                   const void* enc_out, float* dtoken_w, float* dtoken_b, float* const* enc_grads, float* dhead_w, float* dhead_b,
+                                   void* dh, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes, float attn_p,
+                                   float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    HYB_CHECK_ARG(dloss && logits && target);
+    return temporal_bwd_impl(dtype, nullptr, logits, target, dloss, token_w, enc_params, head_w, mask, feat, enc_saved, enc_out, dtoken_w, dtoken_b,
+                             enc_grads, dhead_w, dhead_b, dh, B, S, HW, C, Cp, D, Hid, L, H, classes, attn_p, layer_p, seed, seed_inc, workspace,
+                             workspace_bytes, stream);
 }

@@ -63,6 +63,14 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 // one more Linear weight (+ bias) gradient for the encoder backward's final multi-matrix launch (hyb_encoder_bwd_impl): dW[N][K] = dy^T x
 struct HybDwExtra { const void* dy; const void* x; float* dW; float* db; int N, K, lddy, ldx; };
 
+// a rider of that launch: out[c] = sum over `rows` partial rows of n floats each (part[r*n + c], rows in ascending order); columns < split go
+// to out0[c], the others to out1[c - split] (LayerNorm: n = 2D, split = D -> dgamma, dbeta; the head: n = C*D + C, split = C*D -> dW, db)
+struct HybDwRider { const float* part; float* out0; float* out1; int rows; long long n, split; };
+
+// operands of the last encoder layer's second LayerNorm, handed to the fused temporal tail launches (model.hip -> fused.hip -> layernorm.hip)
+struct HybEncTail { const void* f; const void* x1; float* st2; const float* gamma; const float* beta; float eps, out_scale, p_drop; unsigned long long seed; };
+struct HybEncBwdTail { const void* f; const float* stats; const float* gamma; void* dx; void* dskip; float* ln_part; int ln_rows; float out_scale, p_drop; unsigned long long seed; };
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };

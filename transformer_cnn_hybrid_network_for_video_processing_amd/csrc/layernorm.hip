@@ -11,14 +11,13 @@ constexpr int LN_MAXC = 4;        // chunks of 8 features per lane: D <= 64*8*4 
 // Latency is all this kernel has (128 rows of 512 features): every global load of a row -- x, skip, gamma, beta and the dropout counter --
 // is issued before the first wait, so the kernel pays ONE memory round trip (the first version loaded skip / gamma / beta after the two
 // reductions and the counter before anything else: three dependent round trips, 4.2 us hot; reductions by DPP, not ds_bpermute).
+// One token row by one wave (the body of ln_residual_fwd_kernel; also called per row by temporal_tail_fwd_kernel, which is why the two
+// produce the same bits).  ycopy: optional second destination (an LDS image of the row), same values.
 template <typename T>
-__global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              T* __restrict__ y, float* __restrict__ stats, int M, int D, float eps,
-                                                              float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+__device__ __forceinline__ void ln_fwd_row(const T* __restrict__ x, const T* __restrict__ skip, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, T* __restrict__ y, T* ycopy, float* __restrict__ stats, int M, int row,
+                                           int D, float eps, float out_scale, float p_drop, unsigned long long seed,
+                                           const unsigned long long* __restrict__ seed_inc, int lane) {
     const int nchunk = D >> 3;
     Vec8<T> xv[LN_MAXC], sk[LN_MAXC];
     Vec8<float> gm[LN_MAXC], bt[LN_MAXC];
@@ -71,6 +70,81 @@ __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restric
                 o.set(j, v);
             }
             o.store(y + (long long)row * D + ch * 8);
+            if (ycopy) o.store(ycopy + ch * 8);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              T* __restrict__ y, float* __restrict__ stats, int M, int D, float eps,
+                                                              float out_scale, float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    ln_fwd_row<T>(x, skip, gamma, beta, y, nullptr, stats, M, row, D, eps, out_scale, p_drop, seed, seed_inc, lane);
+}
+
+// One token row of the LayerNorm + residual backward by one wave (the loop body of ln_residual_bwd_kernel; temporal_tail_bwd_kernel calls it
+// with the row's upstream gradient in LDS: DY_LDS, dyl[D] floats holding T-rounded values -- the same for every token of a clip).
+template <typename T, bool DY_LDS>
+__device__ __forceinline__ void ln_bwd_row(const T* __restrict__ dy, const float* dyl, const T* __restrict__ x, const Vec8<float> (&gmv)[LN_MAXC],
+                                           const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip, int accumulate_dskip,
+                                           float (&dg)[LN_MAXC][8], float (&db)[LN_MAXC][8], int M, int row, int D, float out_scale, float p_drop,
+                                           unsigned long long seed, float inv_keep, int lane) {
+    const int nchunk = D >> 3;
+    Vec8<T> dvv[LN_MAXC], xvv[LN_MAXC], dsv[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {                    // every load of the row before the first wait
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            if (DY_LDS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dvv[c].set(j, dyl[ch * 8 + j]);
+            } else dvv[c].load(dy + (long long)row * D + ch * 8);
+            xvv[c].load(x + (long long)row * D + ch * 8);
+            if (accumulate_dskip) dsv[c].load(dskip + (long long)row * D + ch * 8);
+        }
+    }
+    const float mean = stats[row], rstd = stats[M + row];
+    float gl[LN_MAXC][8], xh[LN_MAXC][8];      // g = d(ln_out) * gamma ; xhat
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            const Vec8<T>& dv = dvv[c];
+            const Vec8<T>& xv = xvv[c];
+            Vec8<T> ds = dsv[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = ch * 8 + j;
+                float d = dv.get(j) * out_scale;
+                if (p_drop > 0.f) d *= dropout_mult(seed, (unsigned long long)row * D + col, p_drop, inv_keep);
+                const float xhat = (xv.get(j) - mean) * rstd;
+                xh[c][j] = xhat;
+                dg[c][j] += d * xhat;
+                db[c][j] += d;
+                const float g = d * gmv[c].get(j);
+                gl[c][j] = g;
+                s1 += g;
+                s2 += g * xhat;
+                ds.set(j, accumulate_dskip ? ds.get(j) + d : d);
+            }
+            ds.store(dskip + (long long)row * D + ch * 8);
+        }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            Vec8<T> o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.set(j, rstd * (gl[c][j] - s1 - xh[c][j] * s2));
+            o.store(dx + (long long)row * D + ch * 8);
         }
     }
 }
@@ -97,57 +171,8 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
         for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += total_waves) {
-        Vec8<T> dvv[LN_MAXC], xvv[LN_MAXC], dsv[LN_MAXC];
-#pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {                    // every load of the row before the first wait
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
-                dvv[c].load(dy + (long long)row * D + ch * 8);
-                xvv[c].load(x + (long long)row * D + ch * 8);
-                if (accumulate_dskip) dsv[c].load(dskip + (long long)row * D + ch * 8);
-            }
-        }
-        const float mean = stats[row], rstd = stats[M + row];
         if (!seeded) { if (p_drop > 0.f && seed_inc) seed += *seed_inc; seeded = true; }      // device-side step counter (fresh mask per replay)
-        float gl[LN_MAXC][8], xh[LN_MAXC][8];      // g = d(ln_out) * gamma ; xhat
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
-                const Vec8<T>& dv = dvv[c];
-                const Vec8<T>& xv = xvv[c];
-                Vec8<T> ds = dsv[c];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int col = ch * 8 + j;
-                    float d = dv.get(j) * out_scale;
-                    if (p_drop > 0.f) d *= dropout_mult(seed, (unsigned long long)row * D + col, p_drop, inv_keep);
-                    const float xhat = (xv.get(j) - mean) * rstd;
-                    xh[c][j] = xhat;
-                    dg[c][j] += d * xhat;
-                    db[c][j] += d;
-                    const float g = d * gmv[c].get(j);
-                    gl[c][j] = g;
-                    s1 += g;
-                    s2 += g * xhat;
-                    ds.set(j, accumulate_dskip ? ds.get(j) + d : d);
-                }
-                ds.store(dskip + (long long)row * D + ch * 8);
-            }
-        }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
-                Vec8<T> o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.set(j, rstd * (gl[c][j] - s1 - xh[c][j] * s2));
-                o.store(dx + (long long)row * D + ch * 8);
-            }
-        }
+        ln_bwd_row<T, false>(dy, nullptr, x, gmv, stats, dx, dskip, accumulate_dskip, dg, db, M, row, D, out_scale, p_drop, seed, inv_keep, lane);
     }
     extern __shared__ float lnred[];
     if (ROWS) {
@@ -232,9 +257,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
         float s = 0.f;
         if (pre && c == wave) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int d = lane + 64 * j; s += d < D ? pooled[d] * w0[j] : 0.f; }      // same order as the loop below
+            for (int j = 0; j < 8; ++j) { const int d = lane + 64 * j; if (d < D) s = fmaf(pooled[d], w0[j], s); }      // same order and rounding as head_logit
         } else {
-            for (int d = lane; d < D; d += 64) s += pooled[d] * W[(long long)c * D + d];
+            for (int d = lane; d < D; d += 64) s = fmaf(pooled[d], W[(long long)c * D + d], s);
         }
         s = wave_sum(s);
         if (lane == 0) logits[b * C + c] = s + (bias ? bias[c] : 0.f);
@@ -246,7 +271,7 @@ __global__ void head_bwd_dx_kernel(const float* __restrict__ W, const float* __r
     const int b = blockIdx.x;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += dlogits[b * C + c] * W[(long long)c * D + d];
+        for (int c = 0; c < C; ++c) s = fmaf(dlogits[b * C + c], W[(long long)c * D + d], s);      // (explicit: the same rounding in every kernel that forms this row)
         const T v = from_f32<T>(s / (float)S);
         for (int t = 0; t < S; ++t) dx[((long long)b * S + t) * D + d] = v;
     }
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ 
         if (d >= D) return;
         for (int b = ((int)blockIdx.y - yblocks) * 4 + (threadIdx.x >> 6); b < B; b += 4 * ((int)gridDim.y - yblocks)) {
             float s = 0.f;
-            for (int c = 0; c < C; ++c) s += dlogits[b * C + c] * W[(long long)c * D + d];
+            for (int c = 0; c < C; ++c) s = fmaf(dlogits[b * C + c], W[(long long)c * D + d], s);
             const T v = from_f32<T>(s / (float)S);
             for (int t = 0; t < S; ++t) dx_rider[((long long)b * S + t) * D + d] = v;
         }
@@ -301,38 +326,175 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const T* __restrict__ 
 }
 
 // ---- cross entropy (mean over the batch) --------------------------------------------------------------
-__global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, float* __restrict__ loss, int B, int C) {
-    __shared__ float part[256];
-    float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
-        const long long t = target[b];
-        // an out-of-range class index (torch raises a device assert) poisons the loss instead of reading out of bounds
-        acc += (t >= 0 && t < C) ? (logf(s) + mx) - logits[b * C + (int)t] : NAN;
-    }
-    part[threadIdx.x] = acc;
+// one clip's loss term from its C logits (any address space); shared by ce_fwd_kernel and the fused temporal tail
+__device__ __forceinline__ float ce_clip_loss(const float* lg, long long t, int C) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(lg[c] - mx);
+    // an out-of-range class index (torch raises a device assert) poisons the loss instead of reading out of bounds
+    return (t >= 0 && t < C) ? (logf(s) + mx) - lg[(int)t] : NAN;
+}
+// one clip's d(loss)/d(logits[c]) for every class c, g = dloss / B
+__device__ __forceinline__ float ce_clip_dlogit(const float* lg, long long t, int C, int c, float g) {
+    float mx = -INFINITY;
+    for (int k = 0; k < C; ++k) mx = fmaxf(mx, lg[k]);
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += expf(lg[k] - mx);
+    const bool ok = t >= 0 && t < C;                          // out of range: NaN gradient row (see ce_clip_loss)
+    return ok ? g * (expf(lg[c] - mx) / s - (c == (int)t ? 1.f : 0.f)) : NAN;
+}
+// mean of the per-clip terms: threads 0..255 of the calling workgroup (every thread of it must call), thread t owns clips t, t+256, ..;
+// a fixed tree -- the same one whether the terms were just computed (ce_fwd_kernel) or come from other workgroups (temporal tail)
+__device__ __forceinline__ void ce_tree_mean(float acc, float* part /* LDS [256] */, float* __restrict__ loss, int B) {
+    if (threadIdx.x < 256) part[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, float* __restrict__ loss, int B, int C) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) acc += ce_clip_loss(logits + (long long)b * C, target[b], C);
+    ce_tree_mean(acc, part, loss, B);
 }
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, const float* __restrict__ dloss,
                               float* __restrict__ dlogits, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[b * C + c]);
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(logits[b * C + c] - mx);
     const float g = dloss[0] / (float)B;
     const long long t = target[b];
-    const bool ok = t >= 0 && t < C;                          // out of range: NaN gradient row (see ce_fwd_kernel)
-    for (int c = 0; c < C; ++c) dlogits[b * C + c] = ok ? g * (expf(logits[b * C + c] - mx) / s - (c == (int)t ? 1.f : 0.f)) : NAN;
+    for (int c = 0; c < C; ++c) dlogits[b * C + c] = ce_clip_dlogit(logits + (long long)b * C, t, C, c, g);
+}
+
+// ---- the tail of the temporal part as ONE launch each way --------------------------------------------------------------------
+// forward: the last encoder layer's second LayerNorm (+ residual, scale, dropout: src L120-123) -> mean over the clip's tokens -> Linear
+// head -> (when a target is given) the clip's cross-entropy term, and the batch mean by the last workgroup to finish.  One workgroup per
+// clip, a wave per token row.  Every per-row / per-clip expression is the device function the stand-alone kernels call (ln_fwd_row,
+// token_mean's order, head_logit, ce_clip_loss, ce_tree_mean): the fused launch produces the bits of the four launches it replaces.
+// A dependent launch costs >= 4.6 us on this chip whatever it computes: these were 4 x ~5 us for 8 x 512 x 8 numbers.
+__device__ __forceinline__ float head_logit(const float* pooled, const float* __restrict__ Wrow, int D, int lane) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(pooled[d], Wrow[d], s);
+    return wave_sum(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void temporal_tail_fwd_kernel(const T* __restrict__ f, const T* __restrict__ x1, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ enc_out, float* __restrict__ stats,
+                                                                int B, int S, int D, float eps, float out_scale, float p_drop, unsigned long long seed,
+                                                                const unsigned long long* __restrict__ seed_inc, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, float* __restrict__ logits, int C,
+                                                                const long long* __restrict__ target, float* __restrict__ loss,
+                                                                float* __restrict__ ce_scratch, int rows_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    float* pooled = reinterpret_cast<float*>(tail_smem);                    // [D]
+    float* lg = pooled + D;                                                  // [64] this clip's logits
+    float* part = lg + 64;                                                   // [256] loss tree
+    T* rows = reinterpret_cast<T*>(part + 256);                              // [S][D] when rows_in_lds
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int M = B * S;
+    for (int s = wave; s < S; s += nwaves)
+        ln_fwd_row<T>(f, x1, gamma, beta, enc_out, rows_in_lds ? rows + (long long)s * D : nullptr, stats, M, b * S + s, D, eps, out_scale, p_drop,
+                      seed, seed_inc, lane);
+    __syncthreads();                                                         // (also makes the rows just stored to enc_out readable by this workgroup)
+    for (int d = tid; d < D; d += blockDim.x) {
+        if (rows_in_lds) {
+            float s = 0.f;
+            for (int t = 0; t < S; ++t) s += to_f32<T>(rows[(long long)t * D + d]);      // token_mean's order
+            pooled[d] = s / (float)S;
+        } else pooled[d] = token_mean(enc_out, b, S, D, d);
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += nwaves) {
+        const float s = head_logit(pooled, W + (long long)c * D, D, lane);
+        if (lane == 0) { const float v = s + (bias ? bias[c] : 0.f); logits[b * C + c] = v; lg[c] = v; }
+    }
+    if (!target) return;
+    __syncthreads();
+    // ce_scratch: [B] per-clip terms, then one ticket word (zero at rest).  Few bytes are dirty in this kernel, so the release / acquire
+    // pair of the memory model (an L2 write-back / invalidate each) is cheap here -- unlike in a streaming kernel (optim.hip).
+    __shared__ int s_last;
+    if (tid == 0) {
+        __hip_atomic_store(ce_scratch + b, ce_clip_loss(lg, target[b], C), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(ce_scratch + B);
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float acc = 0.f;
+    if (tid < 256)
+        for (int i = tid; i < B; i += 256) acc += __hip_atomic_load(ce_scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ce_tree_mean(acc, part, loss, B);
+}
+
+// backward: cross-entropy backward (from the saved logits, when a target is given; else the caller's dlogits) -> head backward (the
+// clip's token-gradient row v = dlogits W / S, its weight / bias gradient terms as one partial row per clip) -> LayerNorm backward of the
+// clip's token rows, whose upstream gradient is v for every token.  One workgroup per clip; writes dx (d LN input), dskip and the
+// LayerNorm's affine-gradient partial rows exactly as ln_residual_bwd_kernel<T, true> does for the launch it replaces (ln_rows rows:
+// clip b writes row b, rows >= B are zero-filled).
+template <typename T>
+__global__ __launch_bounds__(512) void temporal_tail_bwd_kernel(const float* __restrict__ dlogits_in, const float* __restrict__ logits,
+                                                                const long long* __restrict__ target, const float* __restrict__ dloss,
+                                                                const float* __restrict__ W, const T* __restrict__ enc_out, const T* __restrict__ f,
+                                                                const float* __restrict__ gamma, const float* __restrict__ stats, T* __restrict__ dx,
+                                                                T* __restrict__ dskip, float* __restrict__ ln_part, int ln_rows,
+                                                                float* __restrict__ head_part, int B, int S, int D, int C, float out_scale,
+                                                                float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    float* dl = reinterpret_cast<float*>(tail_smem);                         // [64]
+    float* v = dl + 64;                                                      // [D] the clip's token-gradient row (T-rounded values)
+    float* red = v + D;                                                      // [2][D]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int M = B * S, nchunk = D >> 3;
+    Vec8<float> gmv[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) { const int ch = lane + 64 * c; if (ch < nchunk) gmv[c].load(gamma + ch * 8); }
+    if (tid < C) dl[tid] = target ? ce_clip_dlogit(logits + (long long)b * C, target[b], C, tid, dloss[0] / (float)B) : dlogits_in[b * C + tid];
+    __syncthreads();
+    float* hp = head_part + (long long)b * ((long long)C * D + C);
+    for (int d = tid; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(dl[c], W[(long long)c * D + d], s);           // head_bwd_dx_kernel's expression
+        v[d] = to_f32<T>(from_f32<T>(s / (float)S));
+        const float pooled = token_mean(enc_out, b, S, D, d);
+        for (int c = 0; c < C; ++c) hp[(long long)c * D + d] = dl[c] * pooled;
+    }
+    if (tid < C) hp[(long long)C * D + tid] = dl[tid];
+    for (int i = tid; i < 2 * D; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    float dg[LN_MAXC][8], db[LN_MAXC][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    if (p_drop > 0.f && seed_inc) seed += *seed_inc;
+    for (int s = wave; s < S; s += nwaves)
+        ln_bwd_row<T, true>(nullptr, v, f, gmv, stats, dx, dskip, 0, dg, db, M, b * S + s, D, out_scale, p_drop, seed, inv_keep, lane);
+    // the clip's partial row: the waves add their sums in wave order (fixed)
+    for (int w = 0; w < nwaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < LN_MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nchunk) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { red[ch * 8 + j] += dg[c][j]; red[D + ch * 8 + j] += db[c][j]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 2 * D; i += blockDim.x) {
+        ln_part[(long long)b * 2 * D + i] = red[i];
+        for (int r = B + b; r < ln_rows; r += B) ln_part[(long long)r * 2 * D + i] = 0.f;
+    }
 }
 
 }  // namespace
@@ -395,6 +557,47 @@ int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const flo
 }
 int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st) {
     hipLaunchKernelGGL(ln_rows_reduce_kernel, dim3(hyb_cdiv(2 * D, 32)), dim3(1024), 0, st, part, rows, D, dgamma, dbeta);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal (fused.hip): the temporal tail.  hyb_temporal_tail_ok: the shapes the one-workgroup-per-clip kernels take.
+int hyb_temporal_tail_ok(int B, int S, int D, int C, int ln_rows) {
+    return B >= 1 && B <= ln_rows && S >= 1 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC && C >= 1 && C <= 64;
+}
+int hyb_temporal_tail_fwd(int dtype, const void* f, const void* x1, const float* gamma, const float* beta, void* enc_out, float* stats, int B, int S,
+                          int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, const float* W,
+                          const float* bias, float* logits, int C, const long long* target, float* loss, float* ce_scratch, hipStream_t st) {
+    HYB_CHECK_ARG(f && x1 && gamma && beta && enc_out && stats && W && logits && (!target || (loss && ce_scratch)));
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const size_t base = ((size_t)D + 64 + 256) * sizeof(float);
+    const int rows_in_lds = base + (size_t)S * D * es <= 60 * 1024;
+    const size_t lds = base + (rows_in_lds ? (size_t)S * D * es : 0);
+    const int threads = S >= 8 ? 512 : 256;
+    if (dtype == HYB_F32)
+        hipLaunchKernelGGL(temporal_tail_fwd_kernel<float>, dim3(B), dim3(threads), lds, st, (const float*)f, (const float*)x1, gamma, beta, (float*)enc_out, stats, B, S, D,
+                           eps, out_scale, p_drop, seed, seed_inc, W, bias, logits, C, target, loss, ce_scratch, rows_in_lds);
+    else if (dtype == HYB_BF16)
+        hipLaunchKernelGGL(temporal_tail_fwd_kernel<bf16>, dim3(B), dim3(threads), lds, st, (const bf16*)f, (const bf16*)x1, gamma, beta, (bf16*)enc_out, stats, B, S, D,
+                           eps, out_scale, p_drop, seed, seed_inc, W, bias, logits, C, target, loss, ce_scratch, rows_in_lds);
+    else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+int hyb_temporal_tail_bwd(int dtype, const float* dlogits, const float* logits, const long long* target, const float* dloss, const float* W,
+                          const void* enc_out, const void* f, const float* gamma, const float* stats, void* dx, void* dskip, float* ln_part,
+                          int ln_rows, float* head_part, int B, int S, int D, int C, float out_scale, float p_drop, unsigned long long seed,
+                          const unsigned long long* seed_inc, hipStream_t st) {
+    HYB_CHECK_ARG((dlogits || (logits && target && dloss)) && W && enc_out && f && gamma && stats && dx && dskip && ln_part && head_part);
+    const size_t lds = (64 + 3 * (size_t)D) * sizeof(float);
+    const int threads = S >= 8 ? 512 : 256;
+    if (dtype == HYB_F32)
+        hipLaunchKernelGGL(temporal_tail_bwd_kernel<float>, dim3(B), dim3(threads), lds, st, dlogits, logits, target, dloss, W, (const float*)enc_out, (const float*)f, gamma,
+                           stats, (float*)dx, (float*)dskip, ln_part, ln_rows, head_part, B, S, D, C, out_scale, p_drop, seed, seed_inc);
+    else if (dtype == HYB_BF16)
+        hipLaunchKernelGGL(temporal_tail_bwd_kernel<bf16>, dim3(B), dim3(threads), lds, st, dlogits, logits, target, dloss, W, (const bf16*)enc_out, (const bf16*)f, gamma,
+                           stats, (bf16*)dx, (bf16*)dskip, ln_part, ln_rows, head_part, B, S, D, C, out_scale, p_drop, seed, seed_inc);
+    else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -15,7 +15,7 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
                 const void* const* Cmask = nullptr);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
-                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
+                        int nriders, const HybDwRider* riders);
 int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
                          int accumulate, int transposed_b, hipStream_t st);
 
@@ -172,12 +172,35 @@ struct DwGroup {
     int tiles_x, tile_begin;
 };
 constexpr int DW_MAX_GROUPS = 13;          // two encoder layers' six matrices + the frame-token projection
+constexpr int DW_MAX_RIDERS = 3;           // two layers' LayerNorm partial rows + the head's
 struct DwArgs {
     DwGroup g[DW_MAX_GROUPS]; int ngroups, M;
-    // optional riders (the encoder backward's LayerNorm-affine gradients, one per layer): blocks past `tiles` sum ln_rows partial rows of
-    // 2*ln_D floats each
-    int tiles, nriders; const float* ln_part[2]; int ln_rows, ln_D; float* ln_dgamma[2]; float* ln_dbeta[2];
+    // optional riders (HybDwRider, hyb_common.h: fixed-order sums of partial rows -- the encoder backward's LayerNorm-affine gradients, one
+    // per layer, and the head's weight / bias gradient terms): blocks past `tiles`, 256 columns each; rider r starts at block rider_begin[r]
+    int tiles, nriders; HybDwRider rd[DW_MAX_RIDERS]; int rider_begin[DW_MAX_RIDERS + 1];
 };
+// column c of a rider's partial rows, rows in ascending order, eight loads in flight
+__device__ __forceinline__ void dw_rider_block(const DwArgs& args) {
+    int rid = 0;
+#pragma unroll
+    for (int i = 1; i < DW_MAX_RIDERS; ++i)
+        if (i < args.nriders && (int)blockIdx.x >= args.rider_begin[i]) rid = i;
+    const HybDwRider rd = args.rd[rid];
+    const long long c = (long long)((int)blockIdx.x - args.rider_begin[rid]) * 256 + (int)threadIdx.x;
+    if (c >= rd.n) return;
+    const float* col = rd.part + c;
+    float s = 0.f;
+    int r = 0;
+    for (; r + 8 <= rd.rows; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col[(long long)(r + j) * rd.n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; r < rd.rows; ++r) s += col[(long long)r * rd.n];
+    if (c < rd.split) rd.out0[c] = s; else rd.out1[c - rd.split] = s;
+}
 
 // bf16 form of the kernel below without the transposing LDS stores (they conflicted on 83 % of the cycles): the two operand tiles are
 // staged as they lie in memory -- [row m][64 columns], 16-byte loads and stores, ALL of up to 128 rows in one round (one memory latency
@@ -196,26 +219,7 @@ __device__ __forceinline__ void dwt_frag(Frag<bf16>& f, const bf16* tile, int m0
 __global__ __launch_bounds__(256) void gemm_dw_multi_tr_kernel(DwArgs args) {
     __shared__ __attribute__((aligned(16))) bf16 As[DWT_ROWS * DWT_STRIDE];
     __shared__ __attribute__((aligned(16))) bf16 Bs[DWT_ROWS * DWT_STRIDE];
-    if ((int)blockIdx.x >= args.tiles) {                   // rider: column c of the LayerNorm partial rows, fixed order, eight loads in flight
-        const int per = (2 * args.ln_D + 255) / 256;
-        const int rid = ((int)blockIdx.x - args.tiles) / per;
-        const int c = (((int)blockIdx.x - args.tiles) - rid * per) * 256 + (int)threadIdx.x;
-        if (c >= 2 * args.ln_D) return;
-        const float* col = args.ln_part[rid] + c;
-        const long long ld = 2LL * args.ln_D;
-        float s = 0.f;
-        int r = 0;
-        for (; r + 8 <= args.ln_rows; r += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = col[(long long)(r + j) * ld];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
-        }
-        for (; r < args.ln_rows; ++r) s += col[(long long)r * ld];
-        if (c < args.ln_D) args.ln_dgamma[rid][c] = s; else args.ln_dbeta[rid][c - args.ln_D] = s;
-        return;
-    }
+    if ((int)blockIdx.x >= args.tiles) { dw_rider_block(args); return; }
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < DW_MAX_GROUPS; ++i)
@@ -297,26 +301,7 @@ __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
     constexpr int BM = 64, WM = 32, MT = 2;
     __shared__ __attribute__((aligned(16))) T As[BM * LDS_ROW];
     __shared__ __attribute__((aligned(16))) T Bs[BM * LDS_ROW];
-    if ((int)blockIdx.x >= args.tiles) {                   // rider: column c of the LayerNorm partial rows, fixed order, eight loads in flight
-        const int per = (2 * args.ln_D + 255) / 256;
-        const int rid = ((int)blockIdx.x - args.tiles) / per;
-        const int c = (((int)blockIdx.x - args.tiles) - rid * per) * 256 + (int)threadIdx.x;
-        if (c >= 2 * args.ln_D) return;
-        const float* col = args.ln_part[rid] + c;
-        const long long ld = 2LL * args.ln_D;
-        float s = 0.f;
-        int r = 0;
-        for (; r + 8 <= args.ln_rows; r += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = col[(long long)(r + j) * ld];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
-        }
-        for (; r < args.ln_rows; ++r) s += col[(long long)r * ld];
-        if (c < args.ln_D) args.ln_dgamma[rid][c] = s; else args.ln_dbeta[rid][c - args.ln_D] = s;
-        return;
-    }
+    if ((int)blockIdx.x >= args.tiles) { dw_rider_block(args); return; }
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < DW_MAX_GROUPS; ++i)
@@ -771,7 +756,7 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         // its encoder launch, and the two must agree bit for bit
         const void* dy_[1] = {dym}; const void* x_[1] = {x}; float* dW_[1] = {dW}; float* db_[1] = {db};
         const int N_[1] = {N}, K_[1] = {K}, lddy_[1] = {N}, ldx_[1] = {ldx};
-        int rc = hyb_linear_dw_multi(HYB_BF16, 1, dy_, nullptr, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 0, nullptr, 0, 0, nullptr, nullptr);
+        int rc = hyb_linear_dw_multi(HYB_BF16, 1, dy_, nullptr, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 0, nullptr);
         if (rc) return rc;
     } else if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]; the bias gradient (column sums of dym) rides in the same launch
         GemmArgs a{};
@@ -891,8 +876,8 @@ int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const vo
 // Internal: weight + bias gradients of up to 6 Linear layers of different shapes in one launch (see gemm_dw_multi_kernel).
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
-                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta) {
-    if (groups < 1 || groups > DW_MAX_GROUPS || M < 1 || nriders < 0 || nriders > 2) return HYB_E_ARG;
+                        int nriders, const HybDwRider* riders) {
+    if (groups < 1 || groups > DW_MAX_GROUPS || M < 1 || nriders < 0 || nriders > DW_MAX_RIDERS || (nriders > 0 && !riders)) return HYB_E_ARG;
     DwArgs a{};
     int tiles = 0;
     for (int i = 0; i < groups; ++i) {
@@ -903,11 +888,14 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
     }
     a.ngroups = groups; a.M = M; a.tiles = tiles;
     int blocks = tiles;
-    if (nriders > 0 && ln_part && ln_rows > 0 && ln_D > 0 && ln_dgamma && ln_dbeta) {
-        a.nriders = nriders; a.ln_rows = ln_rows; a.ln_D = ln_D;
-        for (int r = 0; r < nriders; ++r) { a.ln_part[r] = ln_part[r]; a.ln_dgamma[r] = ln_dgamma[r]; a.ln_dbeta[r] = ln_dbeta[r]; }
-        blocks += nriders * hyb_cdiv(2 * ln_D, 256);
+    for (int r = 0; r < nriders; ++r) {
+        if (!riders[r].part || riders[r].rows < 1 || riders[r].n < 1 || !riders[r].out0 || (riders[r].split < riders[r].n && !riders[r].out1)) return HYB_E_ARG;
+        a.rd[r] = riders[r];
+        a.rider_begin[r] = blocks;
+        blocks += hyb_cdiv(riders[r].n, 256);
     }
+    a.nriders = nriders;
+    a.rider_begin[nriders] = blocks;
     static const int tr_env = getenv("HYB_DW_TR") ? atoi(getenv("HYB_DW_TR")) : 1;      // (=0: A/B, the transposing-store form)
     bool aligned = true;                                   // 16-byte rows and bases for the straight vector staging
     for (int i = 0; i < groups; ++i)

@@ -21,7 +21,7 @@ int hyb_ln_residual_fwd_inc(int dtype, const void* x, const void* skip, const fl
 int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
-                        int nriders, const float* const* ln_part, int ln_rows, int ln_D, float* const* ln_dgamma, float* const* ln_dbeta);
+                        int nriders, const HybDwRider* riders);
 int hyb_linear_dw_grouped(int dtype, int groups, const void* const* dy, const void* const* mask, const void* x, float* const* dW,
                           float* const* db, int M, int N, int K, int lddy, int ldx, hipStream_t st);
 int hyb_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* out, float* stats, int B, int S, int D, int H, float p_drop,
@@ -225,8 +225,18 @@ extern "C" size_t hyb_encoder_workspace_bytes(int dtype, int B, int S, int D, in
            (S > 64 ? align256(hyb_attention_long_workspace(dtype, B, S, D, H)) : 0);      // scratch of the long-sequence attention backward
 }
 
+int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
+                         int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream,
+                         HybEncTail* tail);
 extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
                                int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream) {
+    return hyb_encoder_fwd_impl(dtype, x, mask, params, out, saved, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, stream, nullptr);
+}
+// tail != NULL (hyb_temporal_fwd): the LAST layer's second LayerNorm is not launched -- the caller's fused tail launch (layernorm.hip:
+// LayerNorm + head + loss) runs it; *tail receives its operands.
+int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const float* const* params, void* out, void* saved, int B, int S,
+                         int D, int Hid, int L, int H, float attn_p, float layer_p, unsigned long long seed, const unsigned long long* seed_inc, void* stream,
+                         HybEncTail* tail) {
     HYB_CHECK_ARG(x && params && out && saved && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(D % 8 == 0 && Hid % 8 == 0);
@@ -283,6 +293,10 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st)); }                        // src L119 (Linear, ReLU)
         { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {base + lay.wc[5]}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, Hid, Hid, Hid, D, 0, 0, st)); }                      // src L119 (Linear)
+        if (tail && i == L - 1) {
+            *tail = HybEncTail{base + lay.f, base + lay.x1, (float*)(base + lay.st2), P[12], P[13], 1e-5f, (float)sqrt(0.5), layer_p, drop_seed(seed, i)};
+            break;
+        }
         HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.f, base + lay.x1, P[12], P[13], y_out, (float*)(base + lay.st2), M, D, 1e-5f,
                                         (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, stream));                          // src L120-123
     }
@@ -292,12 +306,34 @@ extern "C" int hyb_encoder_fwd(int dtype, const void* x, const float* mask, cons
 int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                          const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                          unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
-                         const HybDwExtra* extra);
+                         const HybDwExtra* extra, int tail_done, const HybDwRider* extra_rider);
+// Where the backward of the LAST layer's second LayerNorm reads and writes (hyb_temporal_bwd runs it inside its fused tail launch and then
+// calls hyb_encoder_bwd_impl with tail_done = 1): the same buffers hyb_ln_residual_bwd_rows is given below.
+HybEncBwdTail hyb_encoder_bwd_tail(int dtype, const float* const* params, const void* saved, void* workspace, int B, int S, int D, int Hid, int L, int H,
+                                   float layer_p, unsigned long long seed) {
+    const size_t es = dtype == HYB_F32 ? 4 : 2;
+    const int M = B * S, i = L - 1;
+    const EncLayout lay = enc_layout(dtype, B, S, D, Hid, H);
+    const char* base = (const char*)saved + (size_t)i * lay.layer_bytes;
+    char* ws = (char*)workspace;
+    const size_t md = align256((size_t)M * D * es);
+    const size_t big = align256((size_t)M * (Hid > D ? Hid : D) * es);
+    const size_t lnb = align256((size_t)2 * 32 * 2 * D * sizeof(float));
+    char* q = ws + 4 * md + (size_t)(i & 1) * (md + 3 * md + 2 * big + lnb);        // parity set of the last layer (see hyb_encoder_bwd_impl)
+    HybEncBwdTail t;
+    t.f = base + lay.f; t.stats = (const float*)(base + lay.st2); t.gamma = params[(size_t)i * 14 + 12];
+    t.dx = q;                                     // set.g1
+    t.dskip = ws;                                 // g2
+    t.ln_part = (float*)(q + md + 3 * md + 2 * big);
+    t.ln_rows = hyb_ln_bwd_rows(M);
+    t.out_scale = (float)sqrt(0.5); t.p_drop = layer_p; t.seed = drop_seed(seed, i);
+    return t;
+}
 extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                                const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                                unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
     return hyb_encoder_bwd_impl(dtype, dout, mask, params, grads, saved, dx, B, S, D, Hid, L, H, attn_p, layer_p, seed, seed_inc, workspace,
-                                workspace_bytes, stream, nullptr);
+                                workspace_bytes, stream, nullptr, 0, nullptr);
 }
 // extra != NULL: one more weight gradient whose dy is this function's dx (the frame-token projection of hyb_temporal_bwd) rides in the last
 // multi-matrix launch.  With L <= 2 the weight gradients of ALL layers are that one launch at the end (each layer's operands live in its own
@@ -305,8 +341,10 @@ extern "C" int hyb_encoder_bwd(int dtype, const void* dout, const float* mask, c
 int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const float* const* params, float* const* grads,
                          const void* saved, void* dx, int B, int S, int D, int Hid, int L, int H, float attn_p, float layer_p,
                          unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream,
-                         const HybDwExtra* extra) {
-    HYB_CHECK_ARG(dout && params && grads && saved && dx && workspace && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
+                         const HybDwExtra* extra, int tail_done, const HybDwRider* extra_rider) {
+    // tail_done: the caller has already run the last layer's LN2 backward (fused tail launch) into the buffers hyb_encoder_bwd_tail names;
+    // extra_rider: one more fixed-order row sum (the head's weight / bias gradient terms) for the final multi-matrix launch
+    HYB_CHECK_ARG((dout || tail_done) && params && grads && saved && dx && workspace && B > 0 && S > 0 && D > 0 && Hid > 0 && L > 0 && H > 0 && D % H == 0);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     if (workspace_bytes < hyb_encoder_workspace_bytes(dtype, B, S, D, Hid, L, H)) return HYB_E_WORKSPACE;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -342,7 +380,7 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
     const bool defer = L <= 2;                              // (two parity sets: the operands of both layers stay valid until the end)
     const void* d_dy[13]; const void* d_mk[13]; const void* d_x[13]; float* d_dW[13]; float* d_db[13];
     int d_N[13], d_K[13], d_lddy[13], d_ldx[13], nd = 0;
-    const float* d_ln[2] = {nullptr, nullptr}; float* d_lg[2] = {nullptr, nullptr}; float* d_lb[2] = {nullptr, nullptr};
+    HybDwRider d_rd[3]; int nrd = 0;
     const void* gA = dout;
     for (int i = L - 1; i >= 0; --i) {
         const char* base = sv + (size_t)i * lay.layer_bytes;
@@ -351,6 +389,7 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
         void* gx = (i == 0) ? dx : gin[i & 1];
         const Set& b = set[i & 1];
         // LN2 + residual + sqrt(.5) + dropout
+        if (!(tail_done && i == L - 1))
         HYB_TRY(hyb_ln_residual_bwd_rows(dtype, gA, base + lay.f, P[12], (const float*)(base + lay.st2), b.g1, g2, 0, b.lnpart, M, D,
                                          (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, st));
         // FFN second Linear: dX = g1 . W2 (pre-transposed copy)
@@ -397,11 +436,11 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
                     d_dy[o + j] = dy_[j]; d_mk[o + j] = mk_[j]; d_x[o + j] = x_[j]; d_dW[o + j] = dW_[j]; d_db[o + j] = db_[j];
                     d_N[o + j] = N_[j]; d_K[o + j] = K_[j]; d_lddy[o + j] = lddy_[j]; d_ldx[o + j] = ldx_[j];
                 }
-                d_ln[nd] = b.lnpart; d_lg[nd] = G[12]; d_lb[nd] = G[13];
+                d_rd[nrd++] = HybDwRider{b.lnpart, G[12], G[13], 2 * lnrows, 2ll * D, (long long)D};
                 ++nd;
             } else {
-                const float* lp[1] = {b.lnpart}; float* lg[1] = {G[12]}; float* lb[1] = {G[13]};
-                HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 1, lp, 2 * lnrows, D, lg, lb));
+                const HybDwRider rd1{b.lnpart, G[12], G[13], 2 * lnrows, 2ll * D, (long long)D};
+                HYB_TRY(hyb_linear_dw_multi(dtype, 6, dy_, mk_, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 1, &rd1));
             }
         }
         gA = gx;
@@ -412,7 +451,9 @@ int hyb_encoder_bwd_impl(int dtype, const void* dout, const float* mask, const f
         d_N[ng] = extra->N; d_K[ng] = extra->K; d_lddy[ng] = extra->lddy; d_ldx[ng] = extra->ldx;
         ++ng;
     }
+    if (extra_rider) d_rd[nrd++] = *extra_rider;
     if (ng > 0)
-        HYB_TRY(hyb_linear_dw_multi(dtype, ng, d_dy, d_mk, d_x, d_dW, d_db, d_N, d_K, d_lddy, d_ldx, M, st, defer ? nd : 0, d_ln, 2 * lnrows, D, d_lg, d_lb));
+        HYB_TRY(hyb_linear_dw_multi(dtype, ng, d_dy, d_mk, d_x, d_dW, d_db, d_N, d_K, d_lddy, d_ldx, M, st, nrd, d_rd));
+    else if (nrd > 0) return HYB_E_ARG;              // (callers pass a rider only when a final launch exists: L <= 2 or a riding weight gradient)
     return 0;
 }

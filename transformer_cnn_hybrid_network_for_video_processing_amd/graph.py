@@ -45,6 +45,9 @@ class GraphedTrainStep:
         if not hasattr(optimizer, "set_step_counter"):
             raise TypeError("GraphedTrainStep needs HybridAdamW (its step number lives on the device)")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        from .modules import HybridCrossEntropyLoss
+        self._fused_loss = (type(criterion) is HybridCrossEntropyLoss and hasattr(model, "forward_temporal_loss")
+                            and os.environ.get("HYB_FUSED_LOSS", "1") != "0")       # (=0: A/B, the criterion as its own two launches)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         dev = x.device
@@ -124,8 +127,12 @@ class GraphedTrainStep:
     # ---- the three pieces (identical code runs eagerly in the warm-up and under capture) -------------------------------
     def _piece_a(self, bind=True):
         h, B = self.model.forward_backbone(self.x)
-        logits = self.model.forward_temporal(h, B, self.mask)
-        loss = self.criterion(logits, self.y)
+        if self._fused_loss:                                   # the loss rides in the temporal part's last launch, its backward in the backward's first
+            loss, logits = self.model.forward_temporal_loss(h, B, self.y, self.mask)
+        else:
+            logits = self.model.forward_temporal(h, B, self.mask)
+            loss = self.criterion(logits, self.y)
+        self.logits = logits.detach()
         if self._one is None:                                  # d(loss)/d(loss): a constant, not a fill launch per step
             self._one = torch.ones_like(loss)
         grads = torch.autograd.grad(loss, [h] + self.t_params, grad_outputs=self._one)

@@ -212,6 +212,17 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         tok = ops.token(h, self.token_proj.weight, self.token_proj.bias, self._dt).reshape(B, h.shape[0] // B, -1)
         return ops.head(enc.forward_compute(tok, mask), self.head.weight, self.head.bias, self._dt)
 
+    def forward_temporal_loss(self, h, B, target, mask=None):
+        """Last pooled map + class indices [B] -> (mean cross-entropy loss, logits): ``HybridCrossEntropyLoss()(forward_temporal(h, B, mask), target)``
+        with the loss inside the temporal part's own launches (hybrid::temporal_ce; same bits).  Plain-structure models only (``_fused()``)."""
+        enc = self.encoder
+        if not self._fused():
+            logits = self.forward_temporal(h, B, mask)
+            return ops.cross_entropy(logits, target), logits
+        return ops.temporal_ce(h, self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias, mask, target, B,
+                               self._dt, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
+                               ops.next_seed())
+
     def backbone_parameters(self):
         return [p for i in range(self.num_stages) for p in getattr(self, f"encoder{i + 1}").parameters()]
 

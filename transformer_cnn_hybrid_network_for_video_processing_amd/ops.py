@@ -859,6 +859,92 @@ def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, e
 
 
 
+_CE_SCRATCH = {}
+
+
+def _ce_scratch(B, device):
+    """The B + 1 floats hyb_temporal_ce_fwd keeps between its workgroups (per-clip loss terms + a ticket word that every call leaves zero):
+    one zero-initialised buffer per (device, stream, B), so calls that share it are stream-ordered."""
+    key = (device.index, _stream(), B)
+    t = _CE_SCRATCH.get(key)
+    if t is None:
+        t = _CE_SCRATCH[key] = torch.zeros(B + 1, dtype=torch.float32, device=device)
+    return t
+
+
+def temporal_ce_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, head_b: Tensor, mask: Optional[Tensor],
+                   target: Tensor, B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int,
+                   seed_inc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """hybrid::temporal + hybrid::cross_entropy in the same launches (hyb_temporal_ce_fwd): -> (loss [], logits, feat, enc_saved, enc_out)."""
+    _require_cuda(h, token_w, head_w, target, *enc_params)
+    h = h.contiguous()
+    N, Hh, Ww, Cp = h.shape
+    S = N // B
+    D, C = token_w.shape
+    classes = head_w.shape[0]
+    _check_attention_limits(S, D, H)
+    if target.dim() != 1 or target.shape[0] != B:
+        raise ValueError(f"expected class indices [B={B}], got {tuple(target.shape)}")
+    target = target.contiguous().to(torch.int64)
+    dev, tdt = h.device, _TORCH_DTYPE[dt]
+    feat = torch.empty(N, Cp, dtype=tdt, device=dev)
+    tok = torch.empty(B, S, D, dtype=tdt, device=dev)
+    enc_out = torch.empty(B, S, D, dtype=tdt, device=dev)
+    saved = _ws(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), dev)
+    logits = torch.empty(B, classes, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    ps = [p.contiguous() for p in enc_params]
+    lib.call("hyb_temporal_ce_fwd", dt, h.data_ptr(), token_w.contiguous().data_ptr(), token_b.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
+             head_w.contiguous().data_ptr(), head_b.contiguous().data_ptr(), _opt_ptr(mask), target.data_ptr(), feat.data_ptr(), tok.data_ptr(),
+             saved.data_ptr(), enc_out.data_ptr(), logits.data_ptr(), loss.data_ptr(), _ce_scratch(B, dev).data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H,
+             classes, float(attn_p), float(layer_p), seed, _opt_ptr(seed_inc), _stream())
+    return loss, logits, feat, saved, enc_out
+
+
+def temporal_ce_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, target, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
+    return (h.new_empty((), dtype=torch.float32),) + temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed)
+
+
+def temporal_ce_bwd_op(dloss: Tensor, logits: Tensor, target: Tensor, token_w: Tensor, enc_params: Sequence[Tensor], head_w: Tensor,
+                       mask: Optional[Tensor], feat: Tensor, saved: Tensor, enc_out: Tensor, Hh: int, Ww: int, dt: int, hid: int, L: int, H: int,
+                       attn_p: float, layer_p: float, seed: int, seed_inc: Optional[Tensor] = None) -> List[Tensor]:
+    """-> [dh, dtoken_w, dtoken_b, dhead_w, dhead_b, denc_param_0, ...]: hybrid::cross_entropy_bwd + hybrid::temporal_bwd in the same launches."""
+    _require_cuda(dloss, logits, feat)
+    B, S, D = enc_out.shape
+    N, Cp = feat.shape
+    C = token_w.shape[1]
+    classes = head_w.shape[0]
+    dev, tdt = feat.device, _TORCH_DTYPE[dt]
+    dl = dloss.contiguous().float().reshape(1)
+    ps = [p.contiguous() for p in enc_params]
+    grads = [torch.empty_like(p) for p in ps]
+    dh = torch.empty(N, Hh, Ww, Cp, dtype=tdt, device=dev)
+    dtw = torch.empty_like(token_w, memory_format=torch.contiguous_format)
+    dtb = torch.empty(D, dtype=torch.float32, device=dev)
+    dhw = torch.empty_like(head_w, memory_format=torch.contiguous_format)
+    dhb = torch.empty(classes, dtype=torch.float32, device=dev)
+    ws = _ws(_query("hyb_temporal_bwd_workspace", dt, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
+    lib.call("hyb_temporal_ce_bwd", dt, dl.data_ptr(), logits.contiguous().data_ptr(), target.contiguous().data_ptr(), token_w.contiguous().data_ptr(),
+             ptr_array([p.data_ptr() for p in ps]), head_w.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), saved.data_ptr(), enc_out.data_ptr(),
+             dtw.data_ptr(), dtb.data_ptr(), ptr_array([g.data_ptr() for g in grads]), dhw.data_ptr(), dhb.data_ptr(), dh.data_ptr(), B, S, Hh * Ww, C, Cp,
+             D, hid, L, H, classes, float(attn_p), float(layer_p), seed, _opt_ptr(seed_inc), ws.data_ptr(), ws.numel(), _stream())
+    return [dh, dtw, dtb, dhw, dhb] + grads
+
+
+def temporal_ce_bwd_fake(dloss, logits, target, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed,
+                         seed_inc=None):
+    return temporal_bwd_fake(logits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed)
+
+
+def temporal_ce(h, token_w, token_b, enc_params, head_w, head_b, mask, target, B, dt, hid, L, H, attn_p, layer_p, seed):
+    """-> (loss, logits): the temporal part and the mean cross-entropy loss as one operator (the loss rides in the temporal part's last launch,
+    its backward in the backward's first)."""
+    S = h.shape[0] // B
+    r = torch.ops.hybrid.temporal_ce(h, token_w, token_b, list(enc_params), head_w, head_b, check_mask(mask, B, S, h.device), target, B, dt, hid, L, H,
+                                     float(attn_p), float(layer_p), seed, step_counter())
+    return r[0], r[1]
+
+
 def temporal(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed):
     S = h.shape[0] // B
     return torch.ops.hybrid.temporal(h, token_w, token_b, list(enc_params), head_w, head_b, check_mask(mask, B, S, h.device), B, dt, hid, L, H,
@@ -1085,6 +1171,32 @@ class _TemporalFn(torch.autograd.Function):
         return (g[0], g[1], g[2], g[3], g[4]) + (None,) * 10 + tuple(g[5:])
 
 
+class _TemporalCeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, token_w, token_b, head_w, head_b, mask, target, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *enc_params):
+        ctx.set_materialize_grads(False)
+        with _below_autograd():
+            loss, logits, feat, saved, enc_out = torch.ops.hybrid.temporal_ce(h, token_w, token_b, enc_params, head_w, head_b, mask, target, B, dt, hid,
+                                                                              L, H, attn_p, layer_p, seed, seed_inc)
+        ctx.seed_inc = seed_inc
+        if mask is None:
+            ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, logits, target, *enc_params)
+        else:
+            ctx.save_for_backward(token_w, head_w, feat, saved, enc_out, logits, target, mask, *enc_params)
+        ctx.cfg = (mask is not None, h.shape[1], h.shape[2], dt, hid, L, H, attn_p, layer_p, seed)
+        ctx.mark_non_differentiable(logits, feat, saved, enc_out)      # (logits: an output for the caller's metrics; the objective is the loss)
+        return loss, logits, feat, saved, enc_out
+
+    @staticmethod
+    def backward(ctx, dloss, *unused):
+        has_mask, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed = ctx.cfg
+        token_w, head_w, feat, saved, enc_out, logits, target, *rest = ctx.saved_tensors
+        mask = rest.pop(0) if has_mask else None
+        g = torch.ops.hybrid.temporal_ce_bwd(dloss, logits, target, token_w, rest, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p,
+                                             layer_p, seed, ctx.seed_inc)
+        return (g[0], g[1], g[2], g[3], g[4]) + (None,) * 11 + tuple(g[5:])
+
+
 _define("nchw_to_nhwc", "(Tensor x, int dt, int cp) -> Tensor", nchw_to_nhwc_op, nchw_to_nhwc_fake, _NchwToNhwcFn.apply)
 _define("nhwc_to_nchw", "(Tensor x, int dt, int C) -> Tensor", nhwc_to_nchw_op, nhwc_to_nchw_fake, _NhwcToNchwFn.apply)
 _define("cast", "(Tensor x, int dt, bool to_t) -> Tensor", cast_op, cast_fake, _CastFn.apply)
@@ -1128,6 +1240,14 @@ _define("temporal", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_par
 _define("temporal_bwd", "(Tensor dlogits, Tensor token_w, Tensor[] enc_params, Tensor head_w, Tensor? mask, Tensor feat, Tensor saved, "
         "Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> Tensor[]",
         temporal_bwd_op, temporal_bwd_fake)
+_define("temporal_ce", "(Tensor h, Tensor token_w, Tensor token_b, Tensor[] enc_params, Tensor head_w, Tensor head_b, Tensor? mask, Tensor target, int B, "
+        "int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+        temporal_ce_op, temporal_ce_fake,
+        lambda h, tw, tb, ps, hw, hb, mask, target, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None: _TemporalCeFn.apply(
+            h, tw, tb, hw, hb, mask, target, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc, *ps))
+_define("temporal_ce_bwd", "(Tensor dloss, Tensor logits, Tensor target, Tensor token_w, Tensor[] enc_params, Tensor head_w, Tensor? mask, Tensor feat, "
+        "Tensor saved, Tensor enc_out, int Hh, int Ww, int dt, int hid, int L, int H, float attn_p, float layer_p, int seed, Tensor? seed_inc=None) "
+        "-> Tensor[]", temporal_ce_bwd_op, temporal_ce_bwd_fake)
 
 
 # ---------------------------------------------------------------------------------------------
