@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void ln_residual_fwd_kernel(const T* __restric
 
 // One token row of the LayerNorm + residual backward by one wave (the loop body of ln_residual_bwd_kernel; temporal_tail_bwd_kernel calls it
 // with the row's upstream gradient in LDS: DY_LDS, dyl[D] floats holding T-rounded values -- the same for every token of a clip).
-template <typename T, bool DY_LDS>
+template <typename T, bool DY_LDS, bool XPRE = false>
 __device__ __forceinline__ void ln_bwd_row(const T* __restrict__ dy, const float* dyl, const T* __restrict__ x, const Vec8<float> (&gmv)[LN_MAXC],
                                            const float* __restrict__ stats, T* __restrict__ dx, T* __restrict__ dskip, int accumulate_dskip,
                                            float (&dg)[LN_MAXC][8], float (&db)[LN_MAXC][8], int M, int row, int D, float out_scale, float p_drop,
-                                           unsigned long long seed, float inv_keep, int lane) {
+                                           unsigned long long seed, float inv_keep, int lane, const Vec8<T>* xpre = nullptr) {
+    // XPRE: the caller loaded the row of x already (xpre[LN_MAXC]), before it formed dyl -- one memory round trip instead of two
     const int nchunk = D >> 3;
     Vec8<T> dvv[LN_MAXC], xvv[LN_MAXC], dsv[LN_MAXC];
 #pragma unroll
@@ -103,7 +104,7 @@ __device__ __forceinline__ void ln_bwd_row(const T* __restrict__ dy, const float
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dvv[c].set(j, dyl[ch * 8 + j]);
             } else dvv[c].load(dy + (long long)row * D + ch * 8);
-            xvv[c].load(x + (long long)row * D + ch * 8);
+            if (XPRE) xvv[c] = xpre[c]; else xvv[c].load(x + (long long)row * D + ch * 8);
             if (accumulate_dskip) dsv[c].load(dskip + (long long)row * D + ch * 8);
         }
     }
@@ -384,12 +385,12 @@ __device__ __forceinline__ float head_logit(const float* pooled, const float* __
 
 template <typename T>
 __global__ __launch_bounds__(512) void temporal_tail_fwd_kernel(const T* __restrict__ f, const T* __restrict__ x1, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, T* __restrict__ enc_out, float* __restrict__ stats,
-                                                                int B, int S, int D, float eps, float out_scale, float p_drop, unsigned long long seed,
-                                                                const unsigned long long* __restrict__ seed_inc, const float* __restrict__ W,
-                                                                const float* __restrict__ bias, float* __restrict__ logits, int C,
-                                                                const long long* __restrict__ target, float* __restrict__ loss,
-                                                                float* __restrict__ ce_scratch, int rows_in_lds) {
+                                                                 const float* __restrict__ beta, T* __restrict__ enc_out, float* __restrict__ stats,
+                                                                 int B, int S, int D, float eps, float out_scale, float p_drop, unsigned long long seed,
+                                                                 const unsigned long long* __restrict__ seed_inc, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, float* __restrict__ logits, int C,
+                                                                 const long long* __restrict__ target, float* __restrict__ loss,
+                                                                 float* __restrict__ ce_scratch, int rows_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
     float* pooled = reinterpret_cast<float*>(tail_smem);                    // [D]
     float* lg = pooled + D;                                                  // [64] this clip's logits
@@ -397,6 +398,13 @@ __global__ __launch_bounds__(512) void temporal_tail_fwd_kernel(const T* __restr
     T* rows = reinterpret_cast<T*>(part + 256);                              // [S][D] when rows_in_lds
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int M = B * S;
+    // this wave's first class: its weight row does not depend on the tokens -- requested before the LayerNorm rows (a latency-bound kernel: one
+    // memory round trip fewer on the critical path), up to 8 x 64 features in registers
+    float w0[8];
+    const bool pre = wave < C && D <= 512;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w0[j] = (pre && lane + 64 * j < D) ? W[(long long)wave * D + lane + 64 * j] : 0.f;
+    const float bias0 = (pre && bias) ? bias[wave] : 0.f;
     for (int s = wave; s < S; s += nwaves)
         ln_fwd_row<T>(f, x1, gamma, beta, enc_out, rows_in_lds ? rows + (long long)s * D : nullptr, stats, M, b * S + s, D, eps, out_scale, p_drop,
                       seed, seed_inc, lane);
@@ -410,18 +418,27 @@ __global__ __launch_bounds__(512) void temporal_tail_fwd_kernel(const T* __restr
     }
     __syncthreads();
     for (int c = wave; c < C; c += nwaves) {
-        const float s = head_logit(pooled, W + (long long)c * D, D, lane);
-        if (lane == 0) { const float v = s + (bias ? bias[c] : 0.f); logits[b * C + c] = v; lg[c] = v; }
+        float s;
+        if (pre && c == wave) {
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int d = lane + 64 * j; if (d < D) s = fmaf(pooled[d], w0[j], s); }      // head_logit's order and rounding
+            s = wave_sum(s);
+        } else s = head_logit(pooled, W + (long long)c * D, D, lane);
+        if (lane == 0) { const float v = s + ((pre && c == wave) ? bias0 : (bias ? bias[c] : 0.f)); logits[b * C + c] = v; lg[c] = v; }
     }
     if (!target) return;
     __syncthreads();
-    // ce_scratch: [B] per-clip terms, then one ticket word (zero at rest).  Few bytes are dirty in this kernel, so the release / acquire
-    // pair of the memory model (an L2 write-back / invalidate each) is cheap here -- unlike in a streaming kernel (optim.hip).
+    // ce_scratch: [B] per-clip terms, then one ticket word (zero at rest).  The term is published by an agent-scope atomic store (performed at
+    // the device's coherence point, not in this XCD's L2), which has completed when vmcnt reaches 0 -- only then is the ticket taken; the last
+    // workgroup reads the terms with agent-scope atomic loads.  (The release / acquire pair of the memory model would be an L2 write-back +
+    // invalidate per workgroup: ~3 us each on this chip, see optim.hip -- as much as the launch this fusion removes.)
     __shared__ int s_last;
     if (tid == 0) {
         __hip_atomic_store(ce_scratch + b, ce_clip_loss(lg, target[b], C), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned int* ticket = reinterpret_cast<unsigned int*>(ce_scratch + B);
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = t == gridDim.x - 1;
         if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -434,39 +451,56 @@ __global__ __launch_bounds__(512) void temporal_tail_fwd_kernel(const T* __restr
 }
 
 // backward: cross-entropy backward (from the saved logits, when a target is given; else the caller's dlogits) -> head backward (the
-// clip's token-gradient row v = dlogits W / S, its weight / bias gradient terms as one partial row per clip) -> LayerNorm backward of the
-// clip's token rows, whose upstream gradient is v for every token.  One workgroup per clip; writes dx (d LN input), dskip and the
-// LayerNorm's affine-gradient partial rows exactly as ln_residual_bwd_kernel<T, true> does for the launch it replaces (ln_rows rows:
-// clip b writes row b, rows >= B are zero-filled).
+// clip's token-gradient row v = dlogits W / S; its weight / bias gradient terms as one partial row per clip) -> LayerNorm backward of the
+// clip's token rows, whose upstream gradient is v for every token.  Grid (row blocks per clip, clips), four waves, a wave per token row:
+// every workgroup of a clip forms the clip's dlogits and v for itself (C x D multiply-adds), the clip's head terms are split among them by
+// column.  Everything a workgroup reads -- its rows of the LayerNorm input, the head weights, the token means -- is requested up front: one
+// memory round trip.  Writes dx (d LN input), dskip and ln_rows affine-gradient partial rows as ln_residual_bwd_kernel<T, true> does for
+// the launch it replaces (workgroup (sb, b) writes row b * nsb + sb; rows no workgroup owns are zero-filled).
 template <typename T>
-__global__ __launch_bounds__(512) void temporal_tail_bwd_kernel(const float* __restrict__ dlogits_in, const float* __restrict__ logits,
+__global__ __launch_bounds__(256) void temporal_tail_bwd_kernel(const float* __restrict__ dlogits_in, const float* __restrict__ logits,
                                                                 const long long* __restrict__ target, const float* __restrict__ dloss,
                                                                 const float* __restrict__ W, const T* __restrict__ enc_out, const T* __restrict__ f,
                                                                 const float* __restrict__ gamma, const float* __restrict__ stats, T* __restrict__ dx,
                                                                 T* __restrict__ dskip, float* __restrict__ ln_part, int ln_rows,
-                                                                float* __restrict__ head_part, int B, int S, int D, int C, float out_scale,
+                                                                float* __restrict__ head_part, int B, int S, int D, int C, int rpw, float out_scale,
                                                                 float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_inc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
     float* dl = reinterpret_cast<float*>(tail_smem);                         // [64]
     float* v = dl + 64;                                                      // [D] the clip's token-gradient row (T-rounded values)
-    float* red = v + D;                                                      // [2][D]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    float* lnred = v + D;                                                    // [4][2][D]
+    const int sb = blockIdx.x, nsb = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = B * S, nchunk = D >> 3;
+    const int s_begin = sb * rpw, s_end = s_begin + rpw < S ? s_begin + rpw : S;
+    // ---- requests first
     Vec8<float> gmv[LN_MAXC];
+    Vec8<T> xpre[LN_MAXC];
+    const int s0 = s_begin + wave;                                           // this wave's first row
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) { const int ch = lane + 64 * c; if (ch < nchunk) gmv[c].load(gamma + ch * 8); }
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            gmv[c].load(gamma + ch * 8);
+            if (s0 < s_end) xpre[c].load(f + (long long)(b * S + s0) * D + ch * 8);
+        }
+    }
+    const int d_first = sb + tid * nsb;                                      // this thread's first head column: its token mean does not wait for dl
+    const float pooled_first = d_first < D ? token_mean(enc_out, b, S, D, d_first) : 0.f;
     if (tid < C) dl[tid] = target ? ce_clip_dlogit(logits + (long long)b * C, target[b], C, tid, dloss[0] / (float)B) : dlogits_in[b * C + tid];
+    if (p_drop > 0.f && seed_inc) seed += *seed_inc;
     __syncthreads();
-    float* hp = head_part + (long long)b * ((long long)C * D + C);
-    for (int d = tid; d < D; d += blockDim.x) {
+    for (int d = tid; d < D; d += 256) {
         float s = 0.f;
         for (int c = 0; c < C; ++c) s = fmaf(dl[c], W[(long long)c * D + d], s);           // head_bwd_dx_kernel's expression
         v[d] = to_f32<T>(from_f32<T>(s / (float)S));
-        const float pooled = token_mean(enc_out, b, S, D, d);
+    }
+    // the clip's head terms, columns [sb, sb + nsb, ...) of this workgroup
+    float* hp = head_part + (long long)b * ((long long)C * D + C);
+    for (int d = d_first; d < D; d += 256 * nsb) {
+        const float pooled = d == d_first ? pooled_first : token_mean(enc_out, b, S, D, d);
         for (int c = 0; c < C; ++c) hp[(long long)c * D + d] = dl[c] * pooled;
     }
-    if (tid < C) hp[(long long)C * D + tid] = dl[tid];
-    for (int i = tid; i < 2 * D; i += blockDim.x) red[i] = 0.f;
+    if (sb == 0 && tid < C) hp[(long long)C * D + tid] = dl[tid];
     __syncthreads();
     float dg[LN_MAXC][8], db[LN_MAXC][8];
 #pragma unroll
@@ -474,26 +508,24 @@ __global__ __launch_bounds__(512) void temporal_tail_bwd_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[c][j] = 0.f; db[c][j] = 0.f; }
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    if (p_drop > 0.f && seed_inc) seed += *seed_inc;
-    for (int s = wave; s < S; s += nwaves)
-        ln_bwd_row<T, true>(nullptr, v, f, gmv, stats, dx, dskip, 0, dg, db, M, b * S + s, D, out_scale, p_drop, seed, inv_keep, lane);
-    // the clip's partial row: the waves add their sums in wave order (fixed)
-    for (int w = 0; w < nwaves; ++w) {
-        if (wave == w) {
+    if (s0 < s_end) ln_bwd_row<T, true, true>(nullptr, v, f, gmv, stats, dx, dskip, 0, dg, db, M, b * S + s0, D, out_scale, p_drop, seed, inv_keep, lane, xpre);
+    for (int s = s0 + 4; s < s_end; s += 4)
+        ln_bwd_row<T, true, false>(nullptr, v, f, gmv, stats, dx, dskip, 0, dg, db, M, b * S + s, D, out_scale, p_drop, seed, inv_keep, lane);
+    // the workgroup's partial row: per-wave slots, then the four waves in a fixed order (as ln_residual_bwd_kernel<T, true>)
+    float* mine = lnred + wave * 2 * D;
 #pragma unroll
-            for (int c = 0; c < LN_MAXC; ++c) {
-                const int ch = lane + 64 * c;
-                if (ch < nchunk) {
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { red[ch * 8 + j] += dg[c][j]; red[D + ch * 8 + j] += db[c][j]; }
-                }
-            }
+            for (int j = 0; j < 8; ++j) { mine[ch * 8 + j] = dg[c][j]; mine[D + ch * 8 + j] = db[c][j]; }
         }
-        __syncthreads();
     }
-    for (int i = tid; i < 2 * D; i += blockDim.x) {
-        ln_part[(long long)b * 2 * D + i] = red[i];
-        for (int r = B + b; r < ln_rows; r += B) ln_part[(long long)r * 2 * D + i] = 0.f;
+    __syncthreads();
+    const int prow = b * nsb + sb, nrows = B * nsb;
+    for (int i = tid; i < 2 * D; i += 256) {
+        ln_part[(long long)prow * 2 * D + i] = (lnred[i] + lnred[2 * D + i]) + (lnred[4 * D + i] + lnred[6 * D + i]);
+        for (int r = nrows + prow; r < ln_rows; r += nrows) ln_part[(long long)r * 2 * D + i] = 0.f;
     }
 }
 
@@ -563,7 +595,7 @@ int hyb_ln_rows_reduce(const float* part, int rows, int D, float* dgamma, float*
 
 // Internal (fused.hip): the temporal tail.  hyb_temporal_tail_ok: the shapes the one-workgroup-per-clip kernels take.
 int hyb_temporal_tail_ok(int B, int S, int D, int C, int ln_rows) {
-    return B >= 1 && B <= ln_rows && S >= 1 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC && C >= 1 && C <= 64;
+    return B >= 1 && B <= ln_rows && S >= 1 && D % 8 == 0 && D <= 1536 && C >= 1 && C <= 64;       // (D: 64 KB of LDS in the backward)
 }
 int hyb_temporal_tail_fwd(int dtype, const void* f, const void* x1, const float* gamma, const float* beta, void* enc_out, float* stats, int B, int S,
                           int D, float eps, float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, const float* W,
@@ -573,7 +605,7 @@ int hyb_temporal_tail_fwd(int dtype, const void* f, const void* x1, const float*
     const size_t base = ((size_t)D + 64 + 256) * sizeof(float);
     const int rows_in_lds = base + (size_t)S * D * es <= 60 * 1024;
     const size_t lds = base + (rows_in_lds ? (size_t)S * D * es : 0);
-    const int threads = S >= 8 ? 512 : 256;
+    const int threads = S >= 8 ? 512 : 256;             // (1024 threads leave 128 registers per lane: the LayerNorm row spills -- measured 13 -> 24 us)
     if (dtype == HYB_F32)
         hipLaunchKernelGGL(temporal_tail_fwd_kernel<float>, dim3(B), dim3(threads), lds, st, (const float*)f, (const float*)x1, gamma, beta, (float*)enc_out, stats, B, S, D,
                            eps, out_scale, p_drop, seed, seed_inc, W, bias, logits, C, target, loss, ce_scratch, rows_in_lds);
@@ -589,14 +621,20 @@ int hyb_temporal_tail_bwd(int dtype, const float* dlogits, const float* logits, 
                           int ln_rows, float* head_part, int B, int S, int D, int C, float out_scale, float p_drop, unsigned long long seed,
                           const unsigned long long* seed_inc, hipStream_t st) {
     HYB_CHECK_ARG((dlogits || (logits && target && dloss)) && W && enc_out && f && gamma && stats && dx && dskip && ln_part && head_part);
-    const size_t lds = (64 + 3 * (size_t)D) * sizeof(float);
-    const int threads = S >= 8 ? 512 : 256;
+    const size_t lds = (64 + 9 * (size_t)D) * sizeof(float);
+    // row blocks per clip: as many as the ln_rows partial rows allow (>= 1: hyb_temporal_tail_ok), four-row granules
+    int nsb = hyb_cdiv(S, 4);
+    if (nsb > ln_rows / B) nsb = ln_rows / B;
+    const int rpw = hyb_cdiv(hyb_cdiv(S, nsb), 4) * 4;
+    nsb = hyb_cdiv(S, rpw);
+    const dim3 grid(nsb, B);
+    if (lds > 64 * 1024) return HYB_E_ARG;
     if (dtype == HYB_F32)
-        hipLaunchKernelGGL(temporal_tail_bwd_kernel<float>, dim3(B), dim3(threads), lds, st, dlogits, logits, target, dloss, W, (const float*)enc_out, (const float*)f, gamma,
-                           stats, (float*)dx, (float*)dskip, ln_part, ln_rows, head_part, B, S, D, C, out_scale, p_drop, seed, seed_inc);
+        hipLaunchKernelGGL(temporal_tail_bwd_kernel<float>, grid, dim3(256), lds, st, dlogits, logits, target, dloss, W, (const float*)enc_out, (const float*)f, gamma,
+                           stats, (float*)dx, (float*)dskip, ln_part, ln_rows, head_part, B, S, D, C, rpw, out_scale, p_drop, seed, seed_inc);
     else if (dtype == HYB_BF16)
-        hipLaunchKernelGGL(temporal_tail_bwd_kernel<bf16>, dim3(B), dim3(threads), lds, st, dlogits, logits, target, dloss, W, (const bf16*)enc_out, (const bf16*)f, gamma,
-                           stats, (bf16*)dx, (bf16*)dskip, ln_part, ln_rows, head_part, B, S, D, C, out_scale, p_drop, seed, seed_inc);
+        hipLaunchKernelGGL(temporal_tail_bwd_kernel<bf16>, grid, dim3(256), lds, st, dlogits, logits, target, dloss, W, (const bf16*)enc_out, (const bf16*)f, gamma,
+                           stats, (bf16*)dx, (bf16*)dskip, ln_part, ln_rows, head_part, B, S, D, C, rpw, out_scale, p_drop, seed, seed_inc);
     else return HYB_E_ARG;
     HYB_LAUNCH_CHECK();
     return 0;
