@@ -162,6 +162,12 @@ int hyb_convstage_fwd(int dtype, int first, const void* x, const float* weight, 
                       float* running_out /* NULL = in-place running statistics; else [2][Co], see hyb_bn_finalize (training only) */,
                       void* workspace, size_t workspace_bytes, void* stream);
 long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop);
+/* The FIRST stage (first = 1) never materialises its raw conv output; its y_raw argument is instead an optional buffer of
+ * hyb_convstage_route_elems() T elements (0 = this dtype / shape keeps no codes: pass NULL) that the forward fills with the stage's
+ * pooling / ReLU routing decisions (4 bits per pooled element: which pixel of the 2x2 window is the first maximum in torch's scan order,
+ * and whether the ReLU passed) and the backward, given the same buffer as y_raw, reads instead of recomputing the convolution to re-derive
+ * them.  NULL on either side: the backward recomputes (same results, bit for bit). */
+long long hyb_convstage_route_elems(int dtype, int N, int H, int W, int Cop);
 size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H, int W, int Cip, int Cop);
 int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw,
                       const void* pooled /* NULL, or the stage's forward output (see hyb_bn_relu_pool_bwd_reduce) */,

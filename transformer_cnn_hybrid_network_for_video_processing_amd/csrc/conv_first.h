@@ -25,6 +25,9 @@ struct S1Args {
     int tilesX, tilesY, numTiles;
     float inv_tpi, inv_tx;   // 1 / (tilesX*tilesY), 1 / tilesX: tile -> (n, ty, tx) without integer division
     int vec_ok;              // x 16-byte aligned and W % 4 == 0: halo rows are loaded as aligned float4
+    unsigned* route;         // NULL, or the routing codes of the apply + pool pass, one 32-bit word per (pooled pixel, 8 channels): [N,H/2,W/2,Cop/8]
+                             // (4 bits per channel: bits 0-1 = which pixel of the 2x2 window is the first maximum, bit 2 = the ReLU passed).
+                             // Written by the wave-private forward pass, read by the wave-private backward pass INSTEAD of recomputing the conv.
 };
 
 // One element of the packed first-layer weights [2][Cop][64] (shared by s1w_pack_kernel and the backbone's one pack launch, conv_fwd.hip):

@@ -549,6 +549,22 @@ size_t hyb_stage1_bwd_workspace(int dtype, int Cop) {
     return 2 * al256((size_t)Cop * 64 * es) + al256(((size_t)Cop * 48 + 2304) * 8) + al256((size_t)S1_BWD_PART * ((size_t)Cop * 48 + 2304) * 4);
 }
 
+// Routing codes (S1Args::route): the forward's wave-private apply pass writes them, the backward's wave-private pass reads them instead of
+// recomputing the conv.  ONE rule for both sides (same frames pointer, same shape, same switches), so a backward never reads codes no
+// forward wrote: 16-bit storage, no ragged 8x16 blocks, aligned float4 rows, 32-bit buffer offsets, both wave-private generations enabled.
+static bool s1_route_ok(size_t es, const float* x, int N, int H, int W, int Ci, int Cop) {
+    static const int fwd_env = getenv("HYB_S1_WAVE") ? atoi(getenv("HYB_S1_WAVE")) : 1;
+    static const int bwd_env = getenv("HYB_S1_WAVE_BWD") ? atoi(getenv("HYB_S1_WAVE_BWD")) : 1;
+    static const int route_env = getenv("HYB_S1_ROUTE") ? atoi(getenv("HYB_S1_ROUTE")) : 1;          // (=0: A/B, the backward recomputes the conv)
+    return route_env && fwd_env && bwd_env && es == 2 && !HYB_X3 && (W % 16 == 0) && (H % 8 == 0) && (((uintptr_t)x & 15) == 0) && (Cop % 8 == 0) &&
+           (long long)N * Ci * H * W * 4 < (1ll << 32) && (long long)N * (H / 2) * (W / 2) * Cop * (long long)es < (1ll << 32);
+}
+// elements of type T the caller provides for the codes: 4 bits per pooled element
+long long hyb_stage1_route_elems(int dtype, int N, int H, int W, int Cop) {
+    if (dtype != HYB_BF16 || HYB_X3 || W % 16 != 0 || H % 8 != 0 || Cop % 8 != 0 || N < 1) return 0;
+    return (long long)N * (H / 2) * (W / 2) * Cop / 4;          // bytes / 2
+}
+
 static int s1_grid(long long numTiles) {
     static const int fwd_wgs = getenv("HYB_S1_FWD_WGS") ? atoi(getenv("HYB_S1_FWD_WGS")) : S1_FWD_WGS;
     long long g = numTiles < fwd_wgs ? numTiles : fwd_wgs;
@@ -560,7 +576,7 @@ template <typename T>
 static int stage1_fwd_t(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co,
                         int Cop, void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out,
-                        int prepacked, hipStream_t st) {
+                        int prepacked, void* route, hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     // packed weights in both K orders; kept for backward when asked (packed_out = [2][Cop][64])
@@ -603,6 +619,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
     a.inv_tpi = 1.0f / (float)(a.tilesX * a.tilesY); a.inv_tx = 1.0f / (float)a.tilesX;
     a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    a.route = (route && wave_private && s1_route_ok(es, x, N, H, W, Ci, Cop)) ? (unsigned*)route : nullptr;
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
     const int gx = s1_grid(numTiles);
@@ -647,7 +664,7 @@ static int stage1_fwd_t(int dtype, const float* x, const float* weight, const fl
 template <typename T>
 static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                         const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                        float* dbeta, const void* packed_in, void* workspace, hipStream_t st) {
+                        float* dbeta, const void* packed_in, void* workspace, const void* route, hipStream_t st) {
     const size_t es = sizeof(T);
     char* ws = (char*)workspace;
     T* wp = (T*)ws;                              ws += al256((size_t)Cop * 64 * es);
@@ -677,6 +694,8 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
     a.tilesX = hyb_cdiv(W, S1_TW); a.tilesY = hyb_cdiv(H, S1_TH);
     a.inv_tpi = 1.0f / (float)(a.tilesX * a.tilesY); a.inv_tx = 1.0f / (float)a.tilesX;
     a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    // (the forward's apply pass was wave-private under the same rule: s1_route_ok covers its conditions)
+    a.route = (route && wave_private && s1_route_ok(es, x, N, H, W, Ci, Cop)) ? (unsigned*)const_cast<void*>(route) : nullptr;
     const long long numTiles = (long long)N * a.tilesX * a.tilesY;
     a.numTiles = (int)numTiles;
     // one pass over x and dpooled (MODE 4), a fixed-order sum of the partial rows, and a finalize on tiny matrices
@@ -705,18 +724,18 @@ static int stage1_bwd_t(const void* dpooled, const float* x, const float* weight
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
                    void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, int prepacked,
-                   hipStream_t st) {
+                   void* route, hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, st);
-    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, st);
+    if (dtype == HYB_F32) return stage1_fwd_t<float>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, route, st);
+    if (dtype == HYB_BF16) return stage1_fwd_t<bf16>(dtype, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci, Co, Cop, pooled, scale_shift, mean_invstd, packed_out, workspace, running_out, prepacked, route, st);
     return HYB_E_ARG;
 }
 
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                   float* dbeta, const void* packed_in, void* workspace, hipStream_t st) {
+                   float* dbeta, const void* packed_in, void* workspace, const void* route, hipStream_t st) {
     if (Ci < 1 || Ci > 4) return HYB_E_ARG;
-    if (dtype == HYB_F32) return stage1_bwd_t<float>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, st);
-    if (dtype == HYB_BF16) return stage1_bwd_t<bf16>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, st);
+    if (dtype == HYB_F32) return stage1_bwd_t<float>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, route, st);
+    if (dtype == HYB_BF16) return stage1_bwd_t<bf16>(dpooled, x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight, dgamma, dbeta, packed_in, workspace, route, st);
     return HYB_E_ARG;
 }

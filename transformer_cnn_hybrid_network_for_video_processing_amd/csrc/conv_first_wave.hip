@@ -65,9 +65,10 @@ __device__ __forceinline__ void s1w_quads_to_frag(Frag<bf16>&, const Quad<bf16>&
 #ifndef S1W_MIN_WAVES
 #define S1W_MIN_WAVES 1
 #endif
-template <typename T, int NT, int MODE, int CI /* 3: RGB frames (no per-channel tests); 0: any Ci <= 4 */>
+template <typename T, int NT, int MODE, int CI /* 3: RGB frames (no per-channel tests); 0: any Ci <= 4 */, bool ROUTE = false /* MODE 1: also write a.route */>
 __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 1) void stage1w_kernel(S1Args a) {
     static_assert(MODE == 0 || MODE == 1, "forward passes only");
+    static_assert(!ROUTE || (MODE == 1 && sizeof(T) == 2), "routing codes: apply pass, 16-bit storage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
     // pooled store (MODE 1): bytes from the block's first window, for sub-block 0
     const unsigned po_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
     const __amdgpu_buffer_rsrc_t prs = hyb_rsrc(MODE == 1 ? a.pooled : (void*)a.x, MODE == 1 ? (unsigned)((long long)a.N * Ho * Wo * Cop * (int)sizeof(T)) : 16u);
+    // routing codes: one word per 8 pooled channels = the pooled tensor's byte offset / 4 (16-bit storage)
+    const __amdgpu_buffer_rsrc_t rrs = hyb_rsrc(ROUTE ? (void*)a.route : (void*)a.x, ROUTE ? (unsigned)((long long)a.N * Ho * Wo * Cop / 2) : 16u);
 
     // block coordinates: scalar counters, advanced by increments (one division per wave, here)
     int n_c = blk_begin / bpi, by_c, bx_c;
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
 #pragma unroll
                 for (int h8 = 0; h8 < NT / 2; ++h8) {
                     Vec8<T> o;
+                    unsigned code = 0;
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) {
                         const int t = h8 * 2 + (e2 >> 1), h = e2 & 1;
@@ -260,10 +264,24 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const float m = __builtin_fmaxf(__builtin_fmaxf(v[0][u], v[1][u]), v[2][u]);                 // v_max3
-                            o.set(e2 * 2 + u, __builtin_fmaxf(__builtin_fmaxf(m, v[3][u]), 0.f));                        // v_max3 with the ReLU's zero
+                            const float om = __builtin_fmaxf(__builtin_fmaxf(m, v[3][u]), 0.f);                          // v_max3 with the ReLU's zero
+                            o.set(e2 * 2 + u, om);
+                            if constexpr (ROUTE) {
+                                // where the backward pass must send this window's gradient: the first maximum in torch's scan order
+                                // (0,0),(0,1),(1,0),(1,1), behind the ReLU -- the decision stage1w_bwd_kernel would otherwise re-derive
+                                // from a recomputed conv (16 MFMAs and ~100 vector instructions per 8x8 pixels there).  Where the ReLU
+                                // passed, the pooled value IS the window maximum: no separate four-way maximum is needed.
+                                unsigned k = v[2][u] == om ? 6u : 7u;
+                                k = v[1][u] == om ? 5u : k;
+                                k = v[0][u] == om ? 4u : k;
+                                k = om > 0.f ? k : 0u;
+                                code |= k << (4 * (e2 * 2 + u));
+                            }
                         }
                     }
                     s1w_store8(prs, win_ok ? pvoff + h8 * 8 * (unsigned)sizeof(T) : OOB, o);
+                    if constexpr (ROUTE)
+                        __builtin_amdgcn_raw_buffer_store_b32(code, rrs, win_ok ? (pvoff + h8 * 8 * (unsigned)sizeof(T)) >> 2 : OOB, 0, 0);
                 }
             }
         }
@@ -302,6 +320,10 @@ __global__ __launch_bounds__(256, (NT == 2 && sizeof(T) == 2) ? S1W_MIN_WAVES : 
 // height is a multiple of 8 and width a multiple of 16 (no ragged blocks: G must not see pixels outside the image); everything else
 // takes the block-level kernel.
 constexpr int S1B_CT = 16;                       // constant table elements: quad {1,0,0,0} (K column 36 = ones), two zero quads, pad
+#ifndef S1B_SCATTER_DEFAULT
+#define S1B_SCATTER_DEFAULT 1                    /* 0: the first form of the gradient routing (A/B: a -DS1B_SCATTER_DEFAULT=0 build) */
+#endif
+constexpr bool S1B_SCATTER = S1B_SCATTER_DEFAULT != 0;
 
 template <typename T> struct S1BTr;
 template <> struct S1BTr<bf16> {
@@ -315,7 +337,8 @@ template <> struct S1BTr<bf16> {
     }
 };
 
-template <typename T, int NT, int CI, bool WITH_G /* false: the forward pass saved G (stage1w_gram_kernel), only S1 is accumulated */>
+template <typename T, int NT, int CI, bool WITH_G /* false: the forward pass saved G (stage1w_gram_kernel), only S1 is accumulated */,
+          bool ROUTED = false /* the forward pass saved its routing codes (a.route): no conv recompute */>
 __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int DS = NT * 16 + 8;                                            // dz row stride (elements): odd multiple of 16 bytes
@@ -380,6 +403,7 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
         f_k1[jy] = (s1w_rowoff(2 * wy + jy + (q == 0 ? 1 : 2)) + 2 * wx + 3 + 2) * 4;
     }
     const unsigned dp_lane = (unsigned)(((wy * Wo + wx) * Cop + co_base + q * (NT * 4)) * (int)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rrs = hyb_rsrc(ROUTED ? (const void*)a.route : (const void*)a.x, ROUTED ? (unsigned)((long long)a.N * Ho * Wo * Cop / 2) : 16u);
     // pixels-as-K operands.  K index i of a 32-pixel step = (row i / 8, column i % 8) of 4 rows; this lane group (q) holds i = 4q .. 4q+3
     // (lo) and 16 + 4q .. (hi = two rows further down); within a 16-lane group lane (pp, qq) supplies pixel i + qq, K columns 4pp .. 4pp+3.
     const int pix_col = 4 * (q & 1) + qq + 3;                                   // image column of pixel (4q + qq), tap column 0
@@ -403,6 +427,7 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
     };
     f32x4 pf[4];
     Vec8<T> gpf[2][NT / 2];                                                    // dpooled of both sub-blocks, one block ahead
+    unsigned cpf[2][NT / 2];                                                   // .. and their routing codes (ROUTED)
     auto prefetch = [&](int n, int by, int bx) {
         const int row0 = by * 8 - 1, col0 = bx * S1W_BW - 4;
         const unsigned bo = (unsigned)((((long long)n * Ci * H + row0) * W + col0) * 4);
@@ -421,6 +446,7 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
                 const unsigned off = dbase + (unsigned)((sb * 4 * Cop + h8 * 8) * (int)sizeof(T));
                 static_assert(sizeof(T) == 2, "16-bit storage only (transposing LDS reads)");
                 gpf[sb][h8] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+                if constexpr (ROUTED) cpf[sb][h8] = __builtin_amdgcn_raw_buffer_load_b32(rrs, off >> 2, 0, 0);
             }
     };
     auto stage = [&](T* img) {
@@ -440,17 +466,19 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
         const T* img = img0;
         const bool more = it + 1 < nblk;
         Vec8<T> gcur[2][NT / 2];
+        unsigned ccur[2][NT / 2];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int h8 = 0; h8 < NT / 2; ++h8) gcur[sb][h8] = gpf[sb][h8];
+            for (int h8 = 0; h8 < NT / 2; ++h8) { gcur[sb][h8] = gpf[sb][h8]; if constexpr (ROUTED) ccur[sb][h8] = cpf[sb][h8]; }
         if (more) prefetch(n_n, by_n_, bx_n_);
         int fx0[4] = {f_k0[0], f_k0[0] + 4, f_k0[1], f_k0[1] + 4}, fx1[4] = {f_k1[0], f_k1[0] + 4, f_k1[1], f_k1[1] + 4};      // [j = 2 jy + jx]
         asm volatile("" : "+v"(fx0[1]), "+v"(fx1[1]), "+v"(fx0[3]), "+v"(fx1[3]));
 #pragma unroll 1
         for (int sb = 0; sb < 2; ++sb) {
-            // ---- conv of the 8x8 sub-block (as in the forward kernels)
+            // ---- conv of the 8x8 sub-block (as in the forward kernels) -- only to re-derive the routing; skipped when the forward pass saved it
             f32x4 acc[4][NT];
+            if constexpr (!ROUTED) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int joff = 8 * sb * 4;
@@ -473,7 +501,71 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
                     acc[j][t] = mma32(w1[t], b1, acc[j][t]);
                 }
             }
-            // ---- route dpooled to the first maximum of each window (torch's scan order) behind the ReLU; park dz [pixel][channel]
+            }
+            // ---- route dpooled to the first maximum of each window (torch's scan order) behind the ReLU; park dz [pixel][channel].
+            // dz has ONE non-zero per (window, channel): the tile is zeroed (four 16-byte LDS stores, no vector arithmetic) and every
+            // gradient element is then written ONCE, as the 16 bits it arrived as, to the slot of its window's arg-max pixel -- a 2-byte
+            // LDS store whose address is picked by three selects (an element whose ReLU was off goes to a pad column).  The first form
+            // built all four pixels' values for every element (4 selects + bf16 repacking per pixel): 195 vector instructions per sub-block
+            // against 28 MFMAs, and the kernel is bound by vector issue.  A wave's LDS operations execute in order.
+            if constexpr (ROUTED) {
+                // the forward pass's decisions (stage1w_kernel<.., ROUTE>): 4 bits per channel, bits 0-1 = arg-max pixel, bit 2 = ReLU passed.
+                // The pixel's byte offset from pixel 0 -- {0, 1, 8, 9} x DS x 2 -- comes out of a four-entry byte table in one register.
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < (64 * NT * 32) / (64 * 16); ++i) {
+                    const int idx = i * 64 + lane, row = idx / (NT * 2), seg = idx % (NT * 2);
+                    *reinterpret_cast<f32x4*>(dyt + row * DS + seg * 8) = z4;
+                }
+                static_assert((DS * 2) % 16 == 0 && 9 * DS * 2 / 16 < 256, "pixel offsets as bytes, in 16-byte units");
+                constexpr unsigned LUT = (0u) | ((DS * 2 / 16) << 8) | ((8 * DS * 2 / 16) << 16) | ((unsigned)(9 * DS * 2 / 16) << 24);
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    const Vec8<T> g = sb == 0 ? gcur[0][h8] : gcur[1][h8];
+                    const unsigned code = sb == 0 ? ccur[0][h8] : ccur[1][h8];
+                    const u32x4 gw = __builtin_bit_cast(u32x4, g.v);
+                    unsigned char* const d0 = reinterpret_cast<unsigned char*>(dyt + ((2 * wy) * 8 + 2 * wx) * DS + q * (NT * 4) + h8 * 8);      // pixel j = 0
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned k8 = (e == 0 ? code << 3 : code >> (4 * e - 3)) & 0x18u;       // 8 x (arg-max pixel)
+                        const unsigned off16 = __builtin_amdgcn_ubfe(LUT, k8, 8u);
+                        if (code & (4u << (4 * e)))
+                            *reinterpret_cast<unsigned short*>(d0 + off16 * 16 + e * 2) = (unsigned short)((e & 1) ? (gw[e >> 1] >> 16) : gw[e >> 1]);
+                    }
+                }
+            } else if (S1B_SCATTER) {
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < (64 * NT * 32) / (64 * 16); ++i) {                   // 64 pixels x NT*16 channels x 2 bytes, 16 bytes per lane and store
+                    const int idx = i * 64 + lane, row = idx / (NT * 2), seg = idx % (NT * 2);
+                    *reinterpret_cast<f32x4*>(dyt + row * DS + seg * 8) = z4;
+                }
+#pragma unroll
+                for (int h8 = 0; h8 < NT / 2; ++h8) {
+                    const Vec8<T> g = sb == 0 ? gcur[0][h8] : gcur[1][h8];
+                    const u32x4 gw = __builtin_bit_cast(u32x4, g.v);
+                    unsigned short* const d0 = reinterpret_cast<unsigned short*>(dyt) + ((2 * wy) * 8 + 2 * wx) * DS + q * (NT * 4) + h8 * 8;      // pixel j = 0
+                    unsigned short* const pad = reinterpret_cast<unsigned short*>(dyt) + NT * 16 + (lane & 7);     // pad columns of pixel row 0: never read
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const int t = h8 * 2 + (e2 >> 1), h = e2 & 1;
+                        const f32x2 sc = c_sc[t][h], sh = c_sh[t][h];
+                        f32x2 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = f32x2{acc[j][t][2 * h], acc[j][t][2 * h + 1]} * sc + sh;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int e = e2 * 2 + u;
+                            const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0][u], v[1][u]), v[2][u]), v[3][u]);
+                            int off = v[2][u] == m ? 8 * DS : 9 * DS;                    // pixel j = (j >> 1) rows, (j & 1) columns from pixel 0
+                            off = v[1][u] == m ? DS : off;
+                            off = v[0][u] == m ? 0 : off;
+                            unsigned short* dst = m > 0.f ? d0 + off + e : pad;
+                            *dst = (unsigned short)((e & 1) ? (gw[e >> 1] >> 16) : gw[e >> 1]);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int h8 = 0; h8 < NT / 2; ++h8) {
                 const Vec8<T> g = sb == 0 ? gcur[0][h8] : gcur[1][h8];
@@ -502,6 +594,7 @@ __global__ __launch_bounds__(256) void stage1w_bwd_kernel(S1Args a) {
                     const int pix = (2 * wy + (j >> 1)) * 8 + 2 * wx + (j & 1);
                     o[j].store(dyt + pix * DS + q * (NT * 4) + h8 * 8);
                 }
+            }
             }
             // ---- S1[co][k] += dz^T P and G += P^T P over the sub-block's 64 pixels (two K steps of 32 pixels = 4 rows x 8)
 #pragma unroll
@@ -940,8 +1033,8 @@ __global__ __launch_bounds__(256) void stage1w_gram_kernel(S1Args a) {
     }
 }
 
-template <typename T, int NT, bool WITH_G>
-int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
+template <typename T, int NT, bool WITH_G, bool ROUTED>
+int s1w_bwd_launch_r(S1Args a, int grid_x, hipStream_t st) {
     constexpr int DS = NT * 16 + 8;
     size_t lds = (size_t)4 * (S1W_IMG + 64 * DS + S1B_CT) * sizeof(T);
     const size_t red = (size_t)4 * (NT * 16 * 48 + 2304) * sizeof(float);
@@ -950,12 +1043,16 @@ int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
     dim3 grid(grid_x, a.Cop / (NT * 16));
     if (lds > 64 * 1024) {
         static HybAttrOnce once3, once0;
-        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_kernel<T, NT, 3, WITH_G> : (const void*)stage1w_bwd_kernel<T, NT, 0, WITH_G>, (int)lds)) return e;
+        if (int e = hyb_set_lds_attr(a.Ci == 3 ? once3 : once0, a.Ci == 3 ? (const void*)stage1w_bwd_kernel<T, NT, 3, WITH_G, ROUTED> : (const void*)stage1w_bwd_kernel<T, NT, 0, WITH_G, ROUTED>, (int)lds)) return e;
     }
-    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 3, WITH_G>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 0, WITH_G>), grid, dim3(256), lds, st, a);
+    if (a.Ci == 3) hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 3, WITH_G, ROUTED>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((stage1w_bwd_kernel<T, NT, 0, WITH_G, ROUTED>), grid, dim3(256), lds, st, a);
     HYB_LAUNCH_CHECK();
     return 0;
+}
+template <typename T, int NT, bool WITH_G>
+int s1w_bwd_launch(S1Args a, int grid_x, hipStream_t st) {
+    return a.route ? s1w_bwd_launch_r<T, NT, WITH_G, true>(a, grid_x, st) : s1w_bwd_launch_r<T, NT, WITH_G, false>(a, grid_x, st);
 }
 
 // packed first-layer weights for the wave-private forward kernels: T [Cop][64], k = slot*4 + c with the slot -> tap map below
@@ -976,6 +1073,14 @@ template <typename T, int NT, int MODE>
 int s1w_launch(S1Args a, int grid_x, hipStream_t st) {
     const size_t lds = (size_t)4 * 2 * S1W_IMG * sizeof(T) + 4 * 2 * NT * 16 * sizeof(float) + 64;
     dim3 grid(grid_x, a.Cop / (NT * 16));
+    if constexpr (MODE == 1 && sizeof(T) == 2) {
+        if (a.route) {
+            if (a.Ci == 3) hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 3, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 0, true>), grid, dim3(256), lds, st, a);
+            HYB_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (a.Ci == 3) hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 3>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((stage1w_kernel<T, NT, MODE, 0>), grid, dim3(256), lds, st, a);
     HYB_LAUNCH_CHECK();

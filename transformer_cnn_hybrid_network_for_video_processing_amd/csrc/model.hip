@@ -37,10 +37,11 @@ size_t hyb_stage1_bwd_workspace(int dtype, int Cop);
 int hyb_stage1_fwd(int dtype, const float* x, const float* weight, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, long long* nbt, int training, float momentum, float eps, int N, int H, int W, int Ci, int Co, int Cop,
                    void* pooled, float* scale_shift, float* mean_invstd, void* packed_out, void* workspace, float* running_out, int prepacked,
-                   hipStream_t st);
+                   void* route, hipStream_t st);
+long long hyb_stage1_route_elems(int dtype, int N, int H, int W, int Cop);
 int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* weight, const float* gamma, const float* scale_shift,
                    const float* mean_invstd, int training, int N, int H, int W, int Ci, int Co, int Cop, float* dweight, float* dgamma,
-                   float* dbeta, const void* packed_in, void* workspace, hipStream_t st);
+                   float* dbeta, const void* packed_in, void* workspace, const void* route, hipStream_t st);
 int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
                             const float* sums, int training, long long count, void* dyraw_out, long long dyraw_blk, float* dw, int N, int H, int W,
                             int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -103,6 +104,8 @@ inline unsigned long long drop_seed(unsigned long long seed, int layer) { return
 // the patches in double (2306 x 8 bytes, counted here in 2-byte elements so that the buffer is large enough for either dtype)
 extern "C" long long hyb_convstage_packed_bwd_elems(int first, int Cip, int Cop) { return first ? (long long)Cop * 128 + 2306 * 4 : (long long)Cip * 9 * Cop; }
 
+extern "C" long long hyb_convstage_route_elems(int dtype, int N, int H, int W, int Cop) { return hyb_stage1_route_elems(dtype, N, H, W, Cop); }
+
 extern "C" size_t hyb_convstage_fwd_workspace(int dtype, int first, int Cip, int Cop) {
     if (first) return hyb_stage1_fwd_workspace(dtype, Cop);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -120,9 +123,9 @@ int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* wei
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(H >= 2 && W >= 2 && Cop % 32 == 0 && Cop >= Co && Co > 0 && N > 0);
     if (workspace_bytes < hyb_convstage_fwd_workspace(dtype, first, Cip, Cop)) return HYB_E_WORKSPACE;
-    if (first)      // stage 1: the raw conv output is never materialised (recomputed in backward), y_raw is ignored
+    if (first)      // stage 1: the raw conv output is never materialised; y_raw, when given, receives the pooling / ReLU routing codes
         return hyb_stage1_fwd(dtype, (const float*)x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, N, H, W, Ci,
-                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, running_out, prepacked_fwd != nullptr,
+                              Co, Cop, pooled, scale_shift, mean_invstd, packed_bwd, workspace, running_out, prepacked_fwd != nullptr, y_raw,
                               (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
@@ -174,7 +177,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     if (workspace_bytes < hyb_convstage_bwd_workspace(dtype, first, N, H, W, Cip, Cop)) return HYB_E_WORKSPACE;
     if (first)
         return hyb_stage1_bwd(dtype, dpooled, (const float*)x, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Co, Cop, dweight,
-                              dgamma, dbeta, packed_bwd, workspace, (hipStream_t)stream);
+                              dgamma, dbeta, packed_bwd, workspace, y_raw, (hipStream_t)stream);
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     char* ws = (char*)workspace;
     float* sums = (float*)ws;                    ws += align256(2 * (size_t)Cop * 4);

@@ -680,7 +680,8 @@ def _backbone_impl(x, weights, gammas, betas, running_means, running_vars, nbts,
     for s in range(S):
         h, w_, Cip, Cop = dims[s]
         Co = chans[s + 1]
-        y_raw = torch.empty(0 if s == 0 else (N, h, w_, Cop), dtype=tdt, device=dev)
+        # (stage 1 keeps no raw conv output: its slot carries the pooling / ReLU routing codes for the backward, where the path writes them)
+        y_raw = torch.empty(_query("hyb_convstage_route_elems", dt, N, h, w_, Cop) if s == 0 else (N, h, w_, Cop), dtype=tdt, device=dev)
         pooled = torch.empty(N, h // 2, w_ // 2, Cop, dtype=tdt, device=dev)
         ss = torch.empty(2, Cop, dtype=torch.float32, device=dev)
         mi = torch.empty(2, Cop, dtype=torch.float32, device=dev)
@@ -689,7 +690,7 @@ def _backbone_impl(x, weights, gammas, betas, running_means, running_vars, nbts,
         per_stage.append((y_raw, pooled, ss, mi, pk, ro))
         params += [weights[s].contiguous().data_ptr(), gammas[s].contiguous().data_ptr(), betas[s].contiguous().data_ptr(),
                    running_means[s].contiguous().data_ptr(), running_vars[s].contiguous().data_ptr()]
-        outs += [None if s == 0 else y_raw.data_ptr(), pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(), pk.data_ptr(),
+        outs += [y_raw.data_ptr() if y_raw.numel() else None, pooled.data_ptr(), ss.data_ptr(), mi.data_ptr(), pk.data_ptr(),
                  ro.data_ptr() if training and not inplace else None]
     ch = _int_array(chans)
     ws = _ws(_query("hyb_backbone_fwd_workspace", dt, S, tuple(chans)), dev)
@@ -713,7 +714,7 @@ def backbone_fake(x, weights, gammas, betas, running_means, running_vars, traini
     for s in range(S):
         h, w_, Cip, Cop = dims[s]
         last = x.new_empty((N, h // 2, w_ // 2, Cop), dtype=tdt)
-        res += [x.new_empty((0,) if s == 0 else (N, h, w_, Cop), dtype=tdt)] + ([last] if s < S - 1 else []) + [
+        res += [x.new_empty((_query("hyb_convstage_route_elems", dt, N, h, w_, Cop),) if s == 0 else (N, h, w_, Cop), dtype=tdt)] + ([last] if s < S - 1 else []) + [
             x.new_empty((2, Cop), dtype=torch.float32), x.new_empty((2, Cop), dtype=torch.float32),
             x.new_empty((_query("hyb_convstage_packed_bwd_elems", int(s == 0), Cip, Cop),), dtype=tdt),
             x.new_empty((2, chans[s + 1]) if training and functional else (0,), dtype=torch.float32)]
@@ -752,7 +753,7 @@ def backbone_bwd_op(dpooled: Tensor, pooled: Tensor, x: Tensor, weights: Sequenc
         gptr += [dw.data_ptr(), dg.data_ptr(), db.data_ptr()]
         pptr += [weights[s].contiguous().data_ptr(), gammas[s].contiguous().data_ptr()]
         sv = saved[5 * s:5 * s + 5]
-        sptr += [None if s == 0 else sv[0].data_ptr(), None if s == 0 else sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), sv[4].data_ptr()]
+        sptr += [sv[0].data_ptr() if sv[0].numel() else None, None if s == 0 else sv[1].data_ptr(), sv[2].data_ptr(), sv[3].data_ptr(), sv[4].data_ptr()]
     ws = _ws(_query("hyb_backbone_bwd_workspace", dt, S, tuple(chans), N, H, W), dev)
     lib.call("hyb_backbone_bwd", dt, S, _int_array(chans), dpooled.data_ptr(), pooled.contiguous().data_ptr(), x.data_ptr(), ptr_array(pptr), ptr_array(sptr), int(training),
              N, H, W, ptr_array(gptr), ws.data_ptr(), ws.numel(), _stream())
