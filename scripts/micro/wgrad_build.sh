@@ -1,5 +1,7 @@
 #!/bin/bash
 # build scripts/micro/wgrad_bench and one library per variant:  wgrad_build.sh name:"flags" ...   (e.g. abl1:"-DHYB_ABL=1")
+# (the sources with the timing-only ablation bits HYB_ABL live here, in scripts/micro/wgrad_variants/conv_wgrad_abl.hip + conv_wgrad_v3_abl.h:
+#  copies of the round-3 product kernels; the product sources carry no ablation branches)
 set -e
 cd "$(dirname "$0")/../.."
 PKG=transformer_cnn_hybrid_network_for_video_processing_amd
@@ -10,7 +12,7 @@ hipcc $HF -c scripts/micro/wgrad_stub.hip -o $OUT/stub.o &
 hipcc -O2 -std=c++17 scripts/micro/wgrad_bench.cpp -o $OUT/wgrad_bench -ldl &
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  ( hipcc $HF $flags -c $PKG/csrc/conv_wgrad.hip -o $OUT/$name.o ) &
+  ( hipcc $HF $flags -c scripts/micro/wgrad_variants/conv_wgrad_abl.hip -o $OUT/$name.o ) &
 done
 wait
 for v in "$@"; do

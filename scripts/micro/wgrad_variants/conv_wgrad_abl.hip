@@ -342,6 +342,9 @@ struct W2Unit {
 
 // the prefetch loads of the tile after next must be ISSUED before the vector work on the next tile (the compiler otherwise sinks
 // them behind it, next to their first use, and their HBM latency lands on the critical path of the following iteration)
+#ifndef HYB_ABL
+#define HYB_ABL 0          // timing-only ablation bits (scripts/micro/wgrad_bench): never set in the product build
+#endif
 #ifdef HYB_NO_KEEP_EARLY
 #define W2_KEEP_EARLY
 #else
@@ -384,6 +387,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
     if (wave >= CW) {
         // ================================================= producers =================================================
         const int pw = wave - CW, ptid = tid - CW * 64;
+        if (HYB_ABL & 64) __builtin_amdgcn_s_setprio(3);
         constexpr int XT = (W2_XW + PW - 1) / PW, DT = (W2_DW + PW - 1) / PW;
         constexpr int NU = 512 / (PW * 64);            // FUSE work items per producer thread (448 units over PW * 64 threads)
         unsigned xoff[10];                           // XT <= 10 entries used (a CI-dependent array bound captured by the lambdas below
@@ -473,6 +477,10 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 union { u32x4 u; bf16x8 v; } o[4];
+                if (HYB_ABL & 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j].u = un[i].y[j].u ^ un[i].g.u;
+                } else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = uoct[i] * 8 + e;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
                 for (int j = 0; j < 4; ++j) {
                     const int ly = 2 * uwy[i] + (j >> 1), lx = 2 * uwx[i] + (j & 1);
                     *reinterpret_cast<bf16x8*>(db + (ly * W2_TW + lx) * 64 + ((uoct[i] ^ w2_swz(ly, lx)) << 3)) = o[j].v;
-                    __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, un[i].pv[j] ? ooff[i][j] : W2_OOB, 0, 0);
+                    if (!(HYB_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, un[i].pv[j] ? ooff[i][j] : W2_OOB, 0, 0);
                 }
             }
         };
@@ -507,7 +515,8 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
         // counted wait leaves the prefetch loads and the stores in flight across the barrier (a __syncthreads() would drain
         // them and add a store round trip to every tile).
         auto publish = [&]() {
-            if (FUSE && NU == 2) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");         // 2 x (5 loads + 4 stores)
+            if (HYB_ABL & (8 | 16 | 32)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (FUSE && NU == 2) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");         // 2 x (5 loads + 4 stores)
             else if (FUSE) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -525,9 +534,9 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
             // even iteration: consumers read buffers 0; fill buffers 1 with t1 (registers ua), prefetch t2 into ub
             {
                 const W2Tile t2 = tl(i + 2);
-                x_dma(t1, xbuf + W2_XBUF);
+                if (!(HYB_ABL & 16)) x_dma(t1, xbuf + W2_XBUF);
                 asm volatile("" ::: "memory");         // the DMAs stay the OLDEST vector-memory operations of the iteration (see publish)
-                if (FUSE) { fuse_load(t2, ub); W2_KEEP_EARLY; fuse_compute(t1, ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
+                if (FUSE) { if (!(HYB_ABL & 32)) fuse_load(t2, ub); W2_KEEP_EARLY; fuse_compute(t1, (HYB_ABL & 32) ? ua : ua, dbuf + W2_DBUF); } else dy_dma(t1, dbuf + W2_DBUF);
                 publish();
                 t1 = t2;
             }
@@ -535,9 +544,9 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
             // odd iteration: consumers read buffers 1; fill buffers 0 with t1 (registers ub), prefetch the next into ua
             {
                 const W2Tile t2 = tl(i + 3);
-                x_dma(t1, xbuf);
+                if (!(HYB_ABL & 16)) x_dma(t1, xbuf);
                 asm volatile("" ::: "memory");
-                if (FUSE) { fuse_load(t2, ua); W2_KEEP_EARLY; fuse_compute(t1, ub, dbuf); } else dy_dma(t1, dbuf);
+                if (FUSE) { if (!(HYB_ABL & 32)) fuse_load(t2, ua); W2_KEEP_EARLY; fuse_compute(t1, (HYB_ABL & 32) ? ua : ub, dbuf); } else dy_dma(t1, dbuf);
                 publish();
                 t1 = t2;
             }
@@ -547,6 +556,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
     }
 
     // =================================================== consumers ===================================================
+    if (HYB_ABL & 128) __builtin_amdgcn_s_setprio(3);
     const int cit = wave % NCIT, coh = wave / NCIT;           // this wave: ci tile cit, co tiles coh*NCT .. coh*NCT + NCT-1
     const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     // fragment addresses (elements).  dy tile pixel (row, col) -> (row*28 + col)*64; x halo pixel -> (row*30 + col)*64.
@@ -588,15 +598,17 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
                   xb + bpix + ((kh + 1) * W2_HW + 4 * j + kw) * CI + boff[kw][((kh + 1) >> 1) & 1]);
         };
         Frag<bf16> a[2][NCT], b[3];
+        if (HYB_ABL & 2) { __syncthreads(); continue; }
 #pragma unroll
         for (int c = 0; c < NCT; ++c) load_a(a[0][c], 0, c);
         load_b(b[0], 0, 0);
         load_b(b[1], 0, 1);
+        if (HYB_ABL & 4) { a[1][0] = a[0][0]; a[1][1] = a[0][1 % NCT]; a[1][2 % NCT] = a[0][2 % NCT]; a[1][3 % NCT] = a[0][3 % NCT]; b[2] = b[0]; }
 #pragma unroll
         for (int st = 0; st < 63; ++st) {
             const int j = st / 9, tap = st % 9;
-            if (st + 2 < 63) load_b(b[(st + 2) % 3], (st + 2) / 9, (st + 2) % 9);
-            if (j < 6 && tap >= 2 && tap < 2 + NCT) load_a(a[(j + 1) & 1][tap - 2], j + 1, tap - 2);
+            if (!(HYB_ABL & 4) && st + 2 < 63) load_b(b[(st + 2) % 3], (st + 2) / 9, (st + 2) % 9);
+            if (!(HYB_ABL & 4) && j < 6 && tap >= 2 && tap < 2 + NCT) load_a(a[(j + 1) & 1][tap - 2], j + 1, tap - 2);
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc[tap][c] = mma32(a[j & 1][c], b[st % 3], acc[tap][c]);
         }
@@ -604,7 +616,7 @@ __global__ __launch_bounds__((CW + PW) * 64) void wgrad_v2_kernel(const bf16* __
 #pragma unroll
         for (int st = 0; st < 63; ++st) {
             const int j = st / 9, tap = st % 9;
-            const bool rb = st + 2 < 63, ra = j < 6 && tap >= 2 && tap < 2 + NCT;
+            const bool rb = !(HYB_ABL & 4) && st + 2 < 63, ra = !(HYB_ABL & 4) && j < 6 && tap >= 2 && tap < 2 + NCT;
             if (ra && rb) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             else if (ra || rb) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
@@ -647,7 +659,7 @@ int w2_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, co
     return w2_launch_cw<FUSE, CI, 4, 4>(grid, hook, st, x, dy, slab, N, H, W, Cip, Cop, tX, tY, nT, fz);
 }
 
-#include "conv_wgrad_v3.h"
+#include "conv_wgrad_v3_abl.h"
 #ifdef HYB_WGRAD_EXPERIMENTS      // scripts/micro/wgrad_variants: the 16-wave and the pipelined 12-wave forms measured in round 3 (not faster)
 #include "conv_wgrad_v4.h"
 #include "conv_wgrad_v5.h"

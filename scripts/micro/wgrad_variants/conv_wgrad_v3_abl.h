@@ -1,8 +1,7 @@
 // Third generation of the fused weight-gradient kernel (bf16, Cip % 64 == 0, Cop % 64 == 0, W % 28 == 0, H % 4 == 0).
 // Included by conv_wgrad.hip inside its anonymous namespace (uses WgradFuse, hyb_rsrc, the W2 tile constants' conventions).
 //
-// What the round-3 ablations of the second generation showed (scripts/micro/wgrad_bench on scripts/micro/wgrad_variants/conv_wgrad_abl.hip -- the copy
-// of these sources that carries the timing-only ablation bits; profiles/r03_wgrad_ablation.txt): with the
+// What the round-3 ablations of the second generation showed (scripts/micro/wgrad_bench, profiles/r03_wgrad_ablation.txt): with the
 // consumer waves idle the producers alone took 66 / 52 us (stages 3 / 4), with the producers idle the consumers alone 58 / 61 us,
 // together 108 / 97 us -- the two halves overlapped badly, and the consumer loop reloaded spilled registers from scratch at its
 // 256-register limit.  Changes:
@@ -148,6 +147,10 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
                 const __amdgpu_buffer_rsrc_t o_rs = hyb_rsrc((bf16*)fz.dyraw_out + obase, (writer && (i == 0 || t.rows > 4)) ? W2_RECORDS : 0u);
                 union { u32x4 u; bf16x8 v; } o[4];
                 if (i == 0 || t.rows > 4) {
+                    if (HYB_ABL & 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j].u = un[i].y[j].u ^ un[i].g.u;
+                    } else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float yf[4], v[4];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, ooff[j] + i * o_i, 0, 0);
+                    if (!(HYB_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b128(o[j].u, o_rs, ooff[j] + i * o_i, 0, 0);
             }
         };
         // End of a producer iteration.  Vector-memory operations of the iteration in issue order: [10 prefetch loads of the tile after
@@ -178,7 +181,9 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
         // the counted wait leaves the stores in flight across the barrier.  (The builtin, not inline assembly: the compiler's own
         // wait-count pass then knows that the prefetched registers are valid and adds no wait of its own in front of their use.)
         auto publish = [&]() {
-            __builtin_amdgcn_s_waitcnt(0x0078);                                                // vmcnt(8) lgkmcnt(0)
+            if (HYB_ABL & 16) __builtin_amdgcn_s_waitcnt(0x0070 | 0xc00f);                    // (ablation: lgkmcnt(0) only)
+            else if (HYB_ABL & 8) __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0078);                                           // vmcnt(8) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         };
         auto tl = [&](int i) { return w3_tile(tbegin + (i < tcount ? i : tcount - 1), tilesX, tilesY, H); };
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
         for (int i = 0; i + 1 < tcount; i += 2) {
             {
                 const W3Tile t1 = tl(i + 1);
-                fuse_load(tl(i + 2), i + 2 < tcount, ua);
-                x_dma(t1, xbuf + W3_XBUF);
+                fuse_load(tl(i + 2), i + 2 < tcount && !(HYB_ABL & 32), ua);
+                if (!(HYB_ABL & 16)) x_dma(t1, xbuf + W3_XBUF);
                 W2_KEEP_EARLY;
                 fuse_compute(t1, ub, dbuf + W3_DBUF);
                 publish();
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
             if (i + 2 >= tcount) break;
             {
                 const W3Tile t2 = tl(i + 2);
-                fuse_load(tl(i + 3), i + 3 < tcount, ub);
-                x_dma(t2, xbuf);
+                fuse_load(tl(i + 3), i + 3 < tcount && !(HYB_ABL & 32), ub);
+                if (!(HYB_ABL & 16)) x_dma(t2, xbuf);
                 W2_KEEP_EARLY;
                 fuse_compute(t2, ua, dbuf);
                 publish();
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(512) void wgrad_v3_kernel(const bf16* __restrict__ 
             const bf16* p = xb + boff[kw] + ((4 * half + kh) * W3_HW + 4 * j) * 64;
             w2_tr(f, p, p + W3_HW * 64);
         };
+        if (HYB_ABL & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); continue; }
         constexpr int RB = W3_RING;                    // x fragments are read RB - 1 steps ahead
         Frag<bf16> a[2], b[RB];
         load_a(a[0], 0);
