@@ -9,6 +9,7 @@
 // small, so these GEMMs are latency-bound; tiles are 64x64 or 32x32 to spread them over more CUs.
 #include <stdlib.h>
 #include "hyb_common.h"
+#include "ln_rows.h"
 
 int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* B, void* const* C, const float* const* bias, int out_f32,
                 int Mo, int No, int R, int lda, int ldb, int ldc, int relu, int accumulate, hipStream_t st, const void* const* Amask = nullptr,
@@ -472,6 +473,97 @@ __global__ __launch_bounds__(NWV * 64) void gemm_nt_splitk_kernel(GemmArgs args)
     }
 }
 
+// The skinny product with LayerNorm + residual as its PROLOGUE:  C = act(LN(x + skip) . B^T + bias), the A operand formed by the workgroup
+// itself.  TransformerEncoder.forward normalises (src L116-117, L120-123) and immediately projects (the feed-forward's first Linear, the next
+// layer's Q / K / V projections); as launches of their own the two LayerNorms of a layer were 2 x 4.8 us for 128 rows (a dependent launch
+// costs >= 4.6 us whatever it computes).  Here the eight waves of a workgroup normalise its 32 rows first -- four rows each, every load in
+// flight at once, the arithmetic of ln_residual_fwd_kernel -- into an LDS image that replaces the global A operand; the column-0 workgroups
+// of group 0 also write the rows and their statistics to global memory (the residual of the next LayerNorm and the backward pass read them).
+// The weight fragments of a wave's first two k-steps are requested before the LayerNorm: their latency and the rows' overlap.
+struct LnPro {
+    const void* x; const void* skip; const float* gamma; const float* beta; void* y; float* stats;
+    float eps, out_scale, p_drop; unsigned long long seed; const unsigned long long* seed_inc;
+};
+constexpr int LNG_PAD = 16;                          // image row stride R + 16 elements: conflict-free 16-byte fragment reads (ds_read_b128 lane groups)
+template <int MAXC>
+__global__ __launch_bounds__(512) void gemm_nt_ln_kernel(GemmArgs args, LnPro ln) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lng_smem[];
+    bf16* const aimg = reinterpret_cast<bf16*>(lng_smem);                          // [32][R + LNG_PAD]
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lng_smem);          // [8][32][33], after the k loop
+    const GemmGroup grp = args.g[blockIdx.z];
+    const bf16* B = (const bf16*)grp.B;
+    bf16* C = (bf16*)grp.C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int R = args.R, ld = R + LNG_PAD;
+    const bf16* brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = n0 + i * 16 + p; if (c > args.No - 1) c = args.No - 1;
+        brow[i] = B + (long long)c * args.ldb + 8 * q;
+    }
+    // weight fragments of this wave's first two k-steps (k0 = 32 wave, 32 wave + 256): independent of the rows
+    Frag<bf16> bpre[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k0 = wave * 32 + s * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (k0 + 8 * q + 8 <= R) frag_load(bpre[s][i], brow[i] + k0); else frag_zero(bpre[s][i]);
+        }
+    }
+    const bool writer = blockIdx.x == 0 && blockIdx.z == 0;
+    ln_fwd_rows_lds<bf16, MAXC, 4>((const bf16*)ln.x, (const bf16*)ln.skip, ln.gamma, ln.beta, writer ? (bf16*)ln.y : nullptr, writer ? ln.stats : nullptr,
+                                   aimg, ld, args.Mo, m0 + wave * 4, wave * 4, R, ln.eps, ln.out_scale, ln.p_drop, ln.seed, ln.seed_inc, lane);
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* arow[2] = {aimg + (long long)p * ld + 8 * q, aimg + (long long)(16 + p) * ld + 8 * q};
+    int step = 0;
+    for (int k0 = wave * 32; k0 < R; k0 += 256, ++step) {
+        Frag<bf16> a[2], b[2];
+        const bool ok = (k0 + 8 * q + 8) <= R;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (ok) frag_load(a[i], arow[i] + k0); else frag_zero(a[i]);
+            if (step < 2) b[i] = step == 0 ? bpre[0][i] : bpre[1][i];
+            else if (ok) frag_load(b[i], brow[i] + k0);
+            else frag_zero(b[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();                                   // every wave has read its fragments: the image may become the partial-tile buffer
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * q + r][j * 16 + p] = acc[i][j][r];
+    __syncthreads();
+    // 1024 outputs: thread -> row, 2 consecutive columns; the wave partials are added in gemm_nt_splitk_kernel's order
+    const int row = tid >> 4, c0 = (tid & 15) * 2;
+    const int mo = m0 + row;
+    if (mo >= args.Mo) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int no = n0 + c0 + c;
+        if (no >= args.No) continue;
+        float v = (red[0][row][c0 + c] + red[1][row][c0 + c]) + (red[2][row][c0 + c] + red[3][row][c0 + c]);
+        v += (red[4][row][c0 + c] + red[5][row][c0 + c]) + (red[6][row][c0 + c] + red[7][row][c0 + c]);
+        if (grp.bias) v += grp.bias[no];
+        if (args.relu) v = fmaxf(v, 0.f);
+        C[(long long)mo * args.ldc + no] = from_f32<bf16>(v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tall GEMM for the pixel side (M = N*H*W rows, up to millions: the im2col convolutions of FCT and Encoder_32K):
 //   C[mo][no] = sum_r A[mo][r] * B[no][r]  (+ bias, ReLU, accumulate), all fp32, exact-fp32 MFMA.
@@ -812,6 +904,29 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
     else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 4>), grid, dim3(256), 0, st, a);
     else return HYB_E_ARG;
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal: hyb_gemm_nt with LayerNorm + residual as the prologue (gemm_nt_ln_kernel): A = dropout((LN(x) * gamma + beta + skip) * out_scale),
+// also written to y (+ stats [2][Mo]) by the column-0 workgroups.  Returns -100 when the shape is not taken (the caller then runs the two
+// launches): bf16 only, few-tile grids (every column tile re-forms its rows), R = D a multiple of 8 up to 1024 with the image in 64 KB of LDS.
+int hyb_gemm_nt_ln(int dtype, int groups, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats, float eps,
+                   float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, const void* const* B, void* const* C,
+                   const float* const* bias, int Mo, int No, int R, int ldb, int ldc, int relu, hipStream_t st) {
+    static const int env = getenv("HYB_GEMM_LN") ? atoi(getenv("HYB_GEMM_LN")) : 1;          // (=0: A/B, LayerNorm as its own launch)
+    const dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), groups);
+    const size_t img = (size_t)32 * (R + LNG_PAD) * sizeof(bf16), red = (size_t)8 * 32 * 33 * sizeof(float);
+    const size_t lds = img > red ? img : red;
+    if (!env || dtype != HYB_BF16 || groups < 1 || groups > 3 || (long long)grid.x * grid.y * grid.z > 256 || R < 256 || R > 1024 || R % 8 != 0 ||
+        ldb % 8 != 0 || lds > 64 * 1024)
+        return -100;
+    GemmArgs a{};
+    for (int i = 0; i < groups; ++i) a.g[i] = GemmGroup{nullptr, B[i], C[i], bias ? bias[i] : nullptr, nullptr, nullptr, nullptr};
+    a.Mo = Mo; a.No = No; a.R = R; a.lda = R; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = 0;
+    const LnPro ln{x, skip, gamma, beta, y, stats, eps, out_scale, p_drop, seed, seed_inc};
+    if (R <= 512) hipLaunchKernelGGL(gemm_nt_ln_kernel<1>, grid, dim3(512), lds, st, a, ln);
+    else hipLaunchKernelGGL(gemm_nt_ln_kernel<2>, grid, dim3(512), lds, st, a, ln);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,9 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
 int hyb_convert_weights(int dtype, int count, const float* const* W, void* const* Wc, void* const* Wt, const int* N, const int* K,
                         const int* ldt, hipStream_t st);
 int hyb_ln_bwd_rows(int M);
+int hyb_gemm_nt_ln(int dtype, int groups, const void* x, const void* skip, const float* gamma, const float* beta, void* y, float* stats, float eps,
+                   float out_scale, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, const void* const* B, void* const* C,
+                   const float* const* bias, int Mo, int No, int R, int ldb, int ldc, int relu, hipStream_t st);
 int hyb_ln_residual_bwd_rows(int dtype, const void* dy, const void* x, const float* gamma, const float* stats, void* dx, void* dskip,
                              int accumulate_dskip, float* part, int M, int D, float out_scale, float p_drop, unsigned long long seed,
                              const unsigned long long* seed_inc, hipStream_t st);
@@ -263,6 +266,7 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
         }
         HYB_TRY(hyb_convert_weights(dtype, 6 * L, Wsrc, Wc, Wt, Ns, Ks, ldt, st));
     }
+    bool ln2_pending = false;
     for (int i = 0; i < L; ++i) {
         char* base = sv + (size_t)i * lay.layer_bytes;
         const float* const* P = params + (size_t)i * 14;
@@ -276,11 +280,27 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
             const int ldt[6] = {3 * D, 3 * D, 3 * D, D, Hid, D};
             HYB_TRY(hyb_convert_weights(dtype, 6, Wsrc, Wc, Wt, Ns, Ks, ldt, st));
         }
-        const void* xs[3] = {x_in, x_in, x_in};
         const void* Wq3[3] = {base + lay.wc[0], base + lay.wc[1], base + lay.wc[2]};
         const float* bs[3] = {P[1], P[3], P[5]};
         void* ys[3] = {base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es};
-        HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, 3 * D, 1, 0, st));                           // src L69-70
+        // Q | K | V projections (src L69-70).  From the second layer on their input is the previous layer's second LayerNorm (src L120-123), which
+        // the projection launch forms for itself when the shape allows (hyb_gemm_nt_ln; it also writes x_in and the statistics): ln2_pending
+        bool projected = false;
+        if (ln2_pending) {
+            const char* pb = sv + (size_t)(i - 1) * lay.layer_bytes;
+            const float* const* PP = params + (size_t)(i - 1) * 14;
+            const int rc = hyb_gemm_nt_ln(dtype, 3, pb + lay.f, pb + lay.x1, PP[12], PP[13], x_in, (float*)(pb + lay.st2), 1e-5f, (float)sqrt(0.5), layer_p,
+                                          drop_seed(seed, i - 1), seed_inc, Wq3, ys, bs, M, D, D, D, 3 * D, 1, st);
+            if (rc == 0) projected = true;
+            else if (rc != -100) return rc;
+            else HYB_TRY(hyb_ln_residual_fwd_inc(dtype, pb + lay.f, pb + lay.x1, PP[12], PP[13], x_in, (float*)(pb + lay.st2), M, D, 1e-5f,
+                                                 (float)sqrt(0.5), layer_p, drop_seed(seed, i - 1), seed_inc, stream));
+            ln2_pending = false;
+        }
+        if (!projected) {
+            const void* xs[3] = {x_in, x_in, x_in};
+            HYB_TRY(hyb_gemm_nt(dtype, 3, xs, Wq3, ys, bs, 0, M, D, D, D, D, 3 * D, 1, 0, st));
+        }
         if (S > 64)
             HYB_TRY(hyb_attention_long_fwd(dtype, base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es, 3 * D, mask,
                                            base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p, attn_seed(seed, i), seed_inc,
@@ -290,16 +310,25 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
                                          attn_seed(seed, i), seed_inc, st));                                          // src L73-84
         { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, D, D, D, D, 0, 0, st)); }                            // src L87
-        HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
-                                        0ull, nullptr, stream));                                                                   // src L116-117
-        { const void* A_[1] = {base + lay.x1}; const void* B_[1] = {base + lay.wc[4]}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
-          HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st)); }                        // src L119 (Linear, ReLU)
+        // first LayerNorm (src L116-117) + the feed-forward's first Linear with ReLU (src L119): one launch when the shape allows
+        {
+            const void* B_[1] = {base + lay.wc[4]}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
+            const int rc = hyb_gemm_nt_ln(dtype, 1, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), 1e-5f, 1.0f, 0.f, 0ull,
+                                          nullptr, B_, C_, b_, M, Hid, D, D, Hid, 1, st);
+            if (rc == -100) {
+                HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), M, D, 1e-5f, 1.0f, 0.f,
+                                                0ull, nullptr, stream));
+                const void* A_[1] = {base + lay.x1};
+                HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st));
+            } else if (rc != 0) return rc;
+        }
         { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {base + lay.wc[5]}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, Hid, Hid, Hid, D, 0, 0, st)); }                      // src L119 (Linear)
         if (tail && i == L - 1) {
             *tail = HybEncTail{base + lay.f, base + lay.x1, (float*)(base + lay.st2), P[12], P[13], 1e-5f, (float)sqrt(0.5), layer_p, drop_seed(seed, i)};
             break;
         }
+        if (i < L - 1) { ln2_pending = true; continue; }           // src L120-123: formed by the next layer's projection launch (above)
         HYB_TRY(hyb_ln_residual_fwd_inc(dtype, base + lay.f, base + lay.x1, P[12], P[13], y_out, (float*)(base + lay.st2), M, D, 1e-5f,
                                         (float)sqrt(0.5), layer_p, drop_seed(seed, i), seed_inc, stream));                          // src L120-123
     }
