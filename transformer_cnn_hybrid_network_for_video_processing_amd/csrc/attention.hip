@@ -164,16 +164,24 @@ __global__ __launch_bounds__(256, SINGLE ? 4 : 2) void attention_fwd_kernel(cons
     const int query = qt * 16 + p;
     f32x4 sT[NTC];
     const int ks = (d.dh + 31) >> 5;
+    // (the loops over the <= 4 k-steps and the <= 4 key tiles have compile-time bounds with run-time predicates: the compiler then issues
+    // every fragment load of a query tile before the first MFMA -- with run-time bounds each k-step waited for its own loads, one memory
+    // round trip after the other: 8.7 us forward / 23.7 us backward for the 64 problems of BASELINE config 4)
+    Frag<T> bq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (s < ks) row_frag(bq[s], qb, d.ld_qkv, query, d.S, s * 32 + 8 * g, d.dh);
 #pragma unroll
     for (int kt = 0; kt < NTC; ++kt) {
         sT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < d.nt) {
-            for (int s = 0; s < ks; ++s) {
-                Frag<T> a, bq;
-                row_frag(a, kb, d.ld_qkv, kt * 16 + p, d.S, s * 32 + 8 * g, d.dh);
-                row_frag(bq, qb, d.ld_qkv, query, d.S, s * 32 + 8 * g, d.dh);
-                sT[kt] = mma32(a, bq, sT[kt]);
-            }
+            Frag<T> a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ks) row_frag(a[s], kb, d.ld_qkv, kt * 16 + p, d.S, s * 32 + 8 * g, d.dh);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ks) sT[kt] = mma32(a[s], bq[s], sT[kt]);
         }
     }
     // scale, mask, softmax over the keys of each query (register + 4-lane reduction)
@@ -282,7 +290,11 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
     seed += seed_step;
     // single-tile sequences (S <= 16): the row fragments of K, Q, V, dO are the same registers in both phases (A and B operands
     // of the 16x16x32 MFMA have the same lane layout), so they are loaded once
-    Frag<T> fk[SINGLE ? 4 : 1], fq[SINGLE ? 4 : 1], fv[SINGLE ? 4 : 1], fg[SINGLE ? 4 : 1];
+    // (several tiles: fq / fg hold the current QUERY tile's rows in phase A and fk / fv the current KEY tile's rows in phase B -- loaded once
+    // per tile, not once per (tile, tile) pair; every loop over k-steps and tiles has a compile-time bound, see attention_fwd_kernel)
+    // (16-bit storage only: fp32 fragments are twice the registers, its multi-tile path keeps one k-step's fragments at a time)
+    constexpr bool HOIST = SINGLE || sizeof(T) == 2;
+    Frag<T> fk[HOIST ? 4 : 1], fq[HOIST ? 4 : 1], fv[HOIST ? 4 : 1], fg[HOIST ? 4 : 1];
 
     // ---------------- phase A: one query tile at a time, all keys (swapped orientation: rows = keys, column = query p)
     for (int qt = wave; qt < d.nt; qt += nw) {
@@ -293,6 +305,15 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         const float* mrow = mbase ? mbase + (long long)(qok ? query : 0) * d.S : nullptr;
         f32x4 pT[NTC], dpT[NTC];
         float dl = 0.f;
+        if constexpr (!SINGLE && HOIST) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ks) {
+                    const int f0 = s * 32 + 8 * g;
+                    row_frag(fq[s], qb, d.ld_qkv, query, d.S, f0, d.dh);
+                    row_frag(fg[s], gb, d.ld_o, query, d.S, f0, d.dh);
+                }
+        }
 #pragma unroll
         for (int kt = 0; kt < NTC; ++kt) {
             pT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -312,6 +333,21 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                         if (s < ks) {
                             pT[kt] = mma32(fk[s], fq[s], pT[kt]);
                             dpT[kt] = mma32(fv[s], fg[s], dpT[kt]);
+                        }
+                } else if constexpr (HOIST) {
+                    Frag<T> ak[4], av[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (s < ks) {
+                            const int f0 = s * 32 + 8 * g;
+                            row_frag(ak[s], kb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
+                            row_frag(av[s], vb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
+                        }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (s < ks) {
+                            pT[kt] = mma32(ak[s], fq[s], pT[kt]);
+                            dpT[kt] = mma32(av[s], fg[s], dpT[kt]);
                         }
                 } else {
                     for (int s = 0; s < ks; ++s) {
@@ -376,6 +412,15 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         f32x4 dkT[SINGLE ? 1 : MAXDT], dvT[SINGLE ? 1 : MAXDT];
 #pragma unroll
         for (int dt = 0; dt < (SINGLE ? 1 : MAXDT); ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (!SINGLE && HOIST) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < ks) {
+                    const int f0 = s * 32 + 8 * g;
+                    row_frag(fk[s], kb, d.ld_qkv, key, d.S, f0, d.dh);
+                    row_frag(fv[s], vb, d.ld_qkv, key, d.S, f0, d.dh);
+                }
+        }
         for (int qt = 0; qt < d.nt; ++qt) {
             f32x4 sN = f32x4{0.f, 0.f, 0.f, 0.f}, dpN = f32x4{0.f, 0.f, 0.f, 0.f};
             if (SINGLE) {
@@ -384,6 +429,21 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                     if (s < ks) {
                         sN = mma32(fq[s], fk[s], sN);
                         dpN = mma32(fg[s], fv[s], dpN);
+                    }
+            } else if constexpr (HOIST) {
+                Frag<T> aq[4], ag[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ks) {
+                        const int f0 = s * 32 + 8 * g;
+                        row_frag(aq[s], qb, d.ld_qkv, qt * 16 + p, d.S, f0, d.dh);
+                        row_frag(ag[s], gb, d.ld_o, qt * 16 + p, d.S, f0, d.dh);
+                    }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < ks) {
+                        sN = mma32(aq[s], fk[s], sN);
+                        dpN = mma32(ag[s], fv[s], dpN);
                     }
             } else {
                 for (int s = 0; s < ks; ++s) {
