@@ -404,6 +404,31 @@ def committed_traffic(kernel, cfgno, dtype):
     return None, None
 
 
+def hooked_kernel_roofline(kernel_id, a, b, flops, name, run_pass, passes=2):
+    """One kernel of a pass against the fp32 matrix peak, timed by the library's own HIP events around that kernel alone (hyb_profile_set) inside
+    real passes -- the last matching launch of each pass."""
+    from transformer_cnn_hybrid_network_for_video_processing_amd._lib import lib
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    torch.cuda.synchronize()
+    lib.call("hyb_profile_set", 0, kernel_id, a, b, e0.cuda_event, e1.cuda_event)
+    ms = 0.0
+    try:
+        for _ in range(passes):
+            run_pass()
+            torch.cuda.synchronize()
+            ms += e0.elapsed_time(e1)
+    finally:
+        lib.call("hyb_profile_clear")
+    ms /= passes
+    if not (ms > 1e-4):
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+            "traffic": None, "ms": ms, "flops_per_launch": flops,
+            "how": f"HIP events recorded by the library around this kernel alone (hyb_profile_set, kernel {kernel_id}, key ({a}, {b})) inside {passes} real passes"}
+
+
 def model_leg(cfgno, dtype, dev, steps, warmup, want_roofline):
     """A short run of one more configuration / precision mode: the same full step as the headline (graph replay when capture works)."""
     _import_torch()
@@ -495,6 +520,15 @@ def fct_leg(dev, reps=5, frames=16, size=224):
     res = {"value": frames / ms * 1e3, "unit": "frames/s", "ms_per_pass": ms, "dtype": "f32",
            "workload": f"FCT training pass (forward + DiceLoss + backward, train mode), frames [{frames},3,{size},{size}]",
            "roofline": entry_point_roofline(ept.totals, 2)}
+    # the heaviest KERNEL inside that entry point, by itself: the dK / dV kernel of the attention backward over the longest sequences
+    mha = [k for k in ept.totals if k[0] == "hyb_fct_mha_bwd"]
+    if mha:
+        (_, (N_, L_, C_, heads_), _), _ = max(((k, v) for k, v in ept.totals.items() if k[0] == "hyb_fct_mha_bwd"), key=lambda kv: kv[1][1])
+        kr = hooked_kernel_roofline(5, int(L_), int(heads_), 4.0 * 2 * N_ * L_ * L_ * C_ / 2, "flash_bwd4_dkv_kernel", train_pass)
+        if kr:
+            kr["what"] = (f"dK / dV kernel of FCT's attention backward, N={N_} L={L_} C={C_} heads={heads_}: recomputes S = QK^T, dP = dO V^T and forms "
+                          "dV = P^T dO, dK = dS^T Q -- 4 L^2 C multiply-adds per image")
+            res["kernel_roofline"] = kr
     from oracle import fct_ref as F
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -537,6 +571,24 @@ def enc32k_leg(dev, reps=5, frames=16):
     res = {"value": frames / ms * 1e3, "unit": "frames/s", "ms_per_pass": ms, "dtype": "f32",
            "workload": f"Encoder_32K training pass (forward + backward, train mode), frames [{frames},3,256,256] -> tokens [{frames},8,4096]; 72 GFLOP per frame",
            "tflops": 72.0 * frames / ms, "roofline": entry_point_roofline(ept.totals, 2)}
+    # the heaviest KERNEL by itself: the implicit-GEMM input gradient of the heaviest stride-1 convolution (gemm_nt_tall_kernel)
+    convs = [(k, v) for k, v in ept.totals.items() if k[0] == "hyb_conv2d_bwd" and k[2] and k[1][6] == 1 and k[1][5] > 1]
+    if convs:
+        (_, key, _), _ = max(convs, key=lambda kv: kv[1][1])
+        N_, H_, W_, Ci_, Co_, k_, stride_, pad_, dil_ = key[:9]
+        Co8 = (Co_ + 7) // 8 * 8
+        Kp = k_ * k_ * Co8                                              # K of the input-gradient GEMM as hyb_conv2d_bwd launches it
+        Ho = (H_ + 2 * pad_ - dil_ * (k_ - 1) - 1) // stride_ + 1
+        Wo = (W_ + 2 * pad_ - dil_ * (k_ - 1) - 1) // stride_ + 1
+        # hyb_conv2d_bwd works in image chunks of <= 512 MB of scratch; the events time the LAST chunk's launch
+        per_img = Ho * Wo * ((k_ * k_ * Ci_ + 7) // 8 * 8 + Co8) * 4
+        nb = max(1, min(N_, (512 << 20) // per_img))
+        last = N_ - nb * ((N_ - 1) // nb)
+        kr = hooked_kernel_roofline(4, int(Ci_), int(Kp), 2.0 * last * H_ * W_ * Ci_ * Kp, "gemm_nt_tall_kernel<4, true>", train_pass)
+        if kr:
+            kr["what"] = (f"input gradient of the {k_}x{k_} convolution {Ci_} -> {Co_} on {last} x {H_}x{W_} pixels (the last image chunk of {N_}) as an "
+                          f"implicit GEMM: rows = input pixels, columns = {Ci_}, K = {Kp}")
+            res["kernel_roofline"] = kr
     from oracle import encoder32k_ref as E
     cores = host_cores()
     torch.set_num_threads(cores)

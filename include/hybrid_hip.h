@@ -61,8 +61,10 @@ int hyb_pad_channels(int c);
  * (a, b) record hipEvent_t ev_start / ev_stop on the launch stream immediately before / after that kernel only.
  *   kernel_id 1: the conv contraction kernel of hyb_conv3x3_fwd -- conv3x3_v2_kernel (bf16, shapes with an asynchronous
  *                variant) or the first-generation conv3x3_nhwc_kernel -- (a = Cip, b = Cop as passed; forward and dgrad launches)
- *   kernel_id 2: the weight-gradient contraction kernel -- wgrad_v2_kernel or the first-generation conv3x3_wgrad_kernel --
+ *   kernel_id 2: the weight-gradient contraction kernel -- wgrad_v3_kernel / wgrad_v2_kernel or the first-generation conv3x3_wgrad_kernel --
  *                (a = Cip, b = Cop)
+ *   kernel_id 4: gemm_nt_tall_kernel, the fp32 pixel-side GEMM behind hyb_conv2d_* / hyb_fct_conv_* (a = output columns, b = K as launched)
+ *   kernel_id 5: flash_bwd4_dkv_kernel, the dK / dV kernel of FCT's attention backward over narrow heads (a = tokens L, b = heads)
  * slot in [0, 16).  hyb_profile_clear() removes all hooks.  The hook table is never touched unless a hook is set, and it is
  * not thread-safe (measurement runs only). */
 int hyb_profile_set(int slot, int kernel_id, int a, int b, void* ev_start, void* ev_stop);

@@ -218,7 +218,7 @@ def test_loss_inside_the_temporal_launches_equals_the_separate_criterion_bitwise
         assert torch.equal(pa.grad, pb.grad), n
     # and against torch's own criterion on the same logits
     want = torch.nn.functional.cross_entropy(logits_b.detach().cpu(), y.cpu())
-    assert abs(float(lb) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    assert abs(float(lb.detach()) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
     # a repeat call leaves the ticket word behind the per-clip terms at zero
     assert int(next(iter(o._CE_SCRATCH.values()))[-1].view(torch.int32).item()) == 0
 

@@ -1413,17 +1413,21 @@ static int flash_bwd_impl(int dtype, const void* q, const void* k, const void* v
     static const int f4_env = getenv("HYB_FLASH_BWD4") ? atoi(getenv("HYB_FLASH_BWD4")) : 1;
     if (f4_env && dhp == 8 && dh_true >= 1 && dh_true <= 8 && L >= 1024) {      // heads of <= 8 features: the 4x4x1 matrix instruction
         const dim3 grid4(hyb_cdiv(L, 256), N * H);
+        HybProfileHook* hook = hyb_find_hook(5, L, H);           // measurement hook (hyb_profile_set): kernel 5 = the dK / dV kernel of this path, keyed by (tokens, heads)
         if (dh_true <= 4) {
             hipLaunchKernelGGL(flash_bwd4_dq_kernel<1>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
                                (const float*)delta_ws, (float*)dq, L, H, ld, scale);
+            if (hook) hipEventRecord(hook->ev0, st);
             hipLaunchKernelGGL(flash_bwd4_dkv_kernel<1>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
                                (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
         } else {
             hipLaunchKernelGGL(flash_bwd4_dq_kernel<2>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
                                (const float*)delta_ws, (float*)dq, L, H, ld, scale);
+            if (hook) hipEventRecord(hook->ev0, st);
             hipLaunchKernelGGL(flash_bwd4_dkv_kernel<2>, grid4, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse,
                                (const float*)delta_ws, (float*)dk, (float*)dv, L, H, ld, scale);
         }
+        if (hook) hipEventRecord(hook->ev1, st);
         HYB_LAUNCH_CHECK();
         return 0;
     }

@@ -896,9 +896,12 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
         const long long blocks = (long long)hyb_cdiv(row_blocks, 8) * tiles_n * 8;
         if (blocks > 0x7fffffff) return HYB_E_ARG;
         const ConvGather none{};
+        HybProfileHook* hook = hyb_find_hook(4, No, R);
+        if (hook) hipEventRecord(hook->ev0, st);
         if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
+        if (hook) hipEventRecord(hook->ev1, st);
     } else if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
@@ -968,9 +971,12 @@ int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, f
     const int tiles_n = hyb_cdiv(Co, nt * 16);
     const long long blocks = (long long)hyb_cdiv(row_blocks, 8) * tiles_n * 8;
     if (blocks > 0x7fffffff) return HYB_E_ARG;
+    HybProfileHook* hook = hyb_find_hook(4, Co, Kp);          // measurement hook (hyb_profile_set): kernel 4 = the tall GEMM, keyed by (columns, K)
+    if (hook) hipEventRecord(hook->ev0, st);
     if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
+    if (hook) hipEventRecord(hook->ev1, st);
     HYB_LAUNCH_CHECK();
     return 0;
 }
