@@ -13,6 +13,8 @@
 #include <type_traits>
 #include "hyb_common.h"
 
+int hyb_wgrad_reduce_multi(int n, const HybSlabInfo* infos, hipStream_t st);
+
 namespace {
 
 constexpr int WG_TH = 8, WG_TW = 16, WG_HW = WG_TW + 2, WG_HH = WG_TH + 2, WG_HP = WG_HH * WG_HW;   // halo 10 x 18
@@ -655,23 +657,63 @@ int w2_launch(dim3 grid, HybProfileHook* hook, hipStream_t st, const bf16* x, co
 
 // few slabs (second-generation kernel: S = 256 / blocks): one thread per output element walks the S slabs; loads are issued
 // eight at a time, the additions keep the slab order
-__global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Co, int Ci,
-                                                               int Cip, long long per_slab) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_slab) return;
-    float s = 0.f;
-    int k = 0;
-    for (; k + 8 <= S; k += 8) {
-        float v[8];
+// The slab sums of up to four stages in ONE launch (they feed nothing but the optimizer, so the backbone backward defers them to its end:
+// three dependent launches of 5.6-11 us become one).  Flat grid; a block is 64 columns x 4 row groups: thread (c, g) sums slabs g, g + 4, ...
+// of its column with eight loads in flight, the four groups are combined through LDS as (g0 + g1) + (g2 + g3).  Every path that sums
+// second / third generation slabs uses this kernel (a single stage = n = 1), so deferred and immediate sums are the same bits.
+struct SlabMulti { HybSlabInfo g[4]; int begin[5]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(SlabMulti a) {
+    __shared__ f32x4 red[4][64];
+    int gi = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = slab[(long long)(k + j) * per_slab + i];
+    for (int i = 1; i < 4; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.begin[i]) gi = i;
+    const HybSlabInfo s = a.g[gi];
+    const int c4 = threadIdx.x & 63, grp = threadIdx.x >> 6;        // thread: 4 consecutive columns (16-byte loads: 1 KB per slab row and block), row group grp
+    const long long i = ((long long)((int)blockIdx.x - a.begin[gi]) * 64 + c4) * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < s.per_slab) {
+        const float* p = s.slab + i;
+        int k = grp;
+        for (; k + 28 < s.S; k += 32) {
+            f32x4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (long long)(k + 4 * j) * s.per_slab);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < s.S; k += 4) acc += *reinterpret_cast<const f32x4*>(p + (long long)k * s.per_slab);
     }
-    for (; k < S; ++k) s += slab[(long long)k * per_slab + i];
-    const int ci = (int)(i % Cip), tap = (int)((i / Cip) % 9), co = (int)(i / ((long long)9 * Cip));
-    if (ci < Ci && co < Co) dw[((long long)co * Ci + ci) * 9 + tap] = s;
+    red[grp][c4] = acc;
+    __syncthreads();
+    if (grp != 0 || i >= s.per_slab) return;
+    const f32x4 v = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long ie = i + e;
+        const int ci = (int)(ie % s.Cip), tap = (int)((ie / s.Cip) % 9), co = (int)(ie / ((long long)9 * s.Cip));
+        if (ci < s.Ci && co < s.Co) s.dw[((long long)co * s.Ci + ci) * 9 + tap] = v[e];
+    }
 }
+
+}  // namespace
+int hyb_wgrad_reduce_multi(int n, const HybSlabInfo* infos, hipStream_t st) {
+    if (n < 1 || n > 4 || !infos) return HYB_E_ARG;
+    SlabMulti a{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!infos[i].slab || !infos[i].dw || infos[i].S < 1 || infos[i].per_slab < 1) return HYB_E_ARG;
+        a.g[i] = infos[i];
+        a.begin[i] = blocks;
+        if (infos[i].per_slab % 4 != 0 || ((uintptr_t)infos[i].slab & 15) != 0) return HYB_E_ARG;      // 16-byte loads
+        blocks += hyb_cdiv(infos[i].per_slab, 256);
+    }
+    a.begin[n] = blocks; a.n = n;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, a);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+namespace {
 
 struct WgradPlan { int S, gy, cit; long long per_slab; };
 
@@ -690,7 +732,8 @@ inline WgradPlan wgrad_plan(int first, int N, int H, int W, int Cip, int Cop) {
 
 template <typename T>
 int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* ws,
-            size_t ws_bytes, hipStream_t st, const WgradFuse* fz = nullptr) {
+            size_t ws_bytes, hipStream_t st, const WgradFuse* fz = nullptr, HybSlabInfo* defer = nullptr) {
+    if (defer) defer->S = 0;
     const WgradPlan p = wgrad_plan(first, N, H, W, Cip, Cop);
     if (ws_bytes < (size_t)p.S * p.per_slab * sizeof(float)) return HYB_E_WORKSPACE;
     float* slab = (float*)ws;
@@ -724,10 +767,9 @@ int wgrad_t(int first, const void* x, const void* dy, float* dw, int N, int H, i
             if (lrc) return lrc;
             HYB_LAUNCH_CHECK();
             if (!dw) return 0;
-            if (S <= 64) hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3(hyb_cdiv(p.per_slab, 256)), dim3(256), 0, st, slab, dw, S, Co, Ci, Cip, p.per_slab);
-            else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hyb_cdiv(p.per_slab, 32)), dim3(1024), 0, st, slab, dw, S, first, Co, Ci, Cop, Cip, p.per_slab);
-            HYB_LAUNCH_CHECK();
-            return 0;
+            const HybSlabInfo info{slab, dw, S, Co, Ci, Cip, p.per_slab};
+            if (defer) { *defer = info; return 0; }              // the caller sums the slabs later (hyb_wgrad_reduce_multi), with other stages'
+            return hyb_wgrad_reduce_multi(1, &info, st);
         }
     }
     const int tilesX = hyb_cdiv(W, WG_TW), tilesY = hyb_cdiv(H, WG_TH);
@@ -772,10 +814,10 @@ int hyb_wgrad_v2_supported(int dtype, int W, int Cip, int Cop) {
 
 int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
                             const float* sums, int training, long long count, void* dyraw_out, long long dyraw_blk, float* dw, int N, int H, int W,
-                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st, HybSlabInfo* defer) {
     WgradFuse fz{y, dp, ss, mi, gamma, sums, dyraw_out, dyraw_blk, Co, training, 1.0f / (float)count};
-    if (dtype == HYB_F32) return wgrad_t<float>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
-    if (dtype == HYB_BF16) return wgrad_t<bf16>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz);
+    if (dtype == HYB_F32) return wgrad_t<float>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz, defer);
+    if (dtype == HYB_BF16) return wgrad_t<bf16>(0, x, nullptr, dw, N, H, W, Ci, Cip, Co, Cop, workspace, workspace_bytes, st, &fz, defer);
     return HYB_E_ARG;
 }
 

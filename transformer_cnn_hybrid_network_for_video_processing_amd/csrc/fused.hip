@@ -31,6 +31,11 @@ int hyb_convstage_fwd_impl(int dtype, int first, const void* x, const float* wei
                            int N, int H, int W, int Ci, int Cip, int Co, int Cop, void* y_raw, void* pooled, float* scale_shift,
                            float* mean_invstd, void* packed_bwd, float* running_out, void* workspace, size_t workspace_bytes, void* stream,
                            const void* prepacked_fwd);
+int hyb_convstage_bwd_impl(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const void* pooled, const float* weight,
+                           const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
+                           int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
+                           const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream, void* slab_ws, HybSlabInfo* defer);
+int hyb_wgrad_reduce_multi(int n, const HybSlabInfo* infos, hipStream_t st);
 int hyb_conv_pack_weight_many(int dtype, int n, const float* const* w, void* const* wp0, void* const* wp1, const int* Co, const int* Ci, const int* Cop,
                               const int* Cip, const float* s1_w, void* s1_wp, int s1_Co, int s1_Ci, int s1_Cop, hipStream_t st);
 
@@ -106,6 +111,23 @@ extern "C" int hyb_backbone_fwd(int dtype, int stages, const int* channels, cons
     return 0;
 }
 
+// The weight-gradient slabs of stages 2.. outlive their stage: their fixed-order sums are ONE launch at the end of the backward (they feed only
+// the optimizer).  Up to four stages are deferred (the first ones met walking backwards); offsets[s] = byte offset of stage s's region.
+static size_t backbone_slab_bytes(int stages, const int* channels, int N, int H, int W, size_t* offsets) {
+    size_t total = 0;
+    int hs[17], wsz[17];
+    { int h = H, w = W; for (int s = 0; s < stages; ++s) { hs[s] = h; wsz[s] = w; h /= 2; w /= 2; } }
+    int deferred = 0;
+    for (int s = stages - 1; s >= 1; --s) {
+        if (offsets) offsets[s] = (size_t)-1;
+        if (deferred >= 4) continue;
+        if (offsets) offsets[s] = total;
+        total += al256(hyb_conv3x3_wgrad_workspace(0, N, hs[s], wsz[s], padc(channels[s]), padc(channels[s + 1])));
+        ++deferred;
+    }
+    return total;
+}
+
 extern "C" size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* channels, int N, int H, int W) {
     if (stages < 1 || !channels || N <= 0) return 0;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
@@ -116,7 +138,7 @@ extern "C" size_t hyb_backbone_bwd_workspace(int dtype, int stages, const int* c
         if (s > 0) dx_bytes = smax(dx_bytes, (size_t)N * h * w * padc(channels[s]) * es);      // d(input of stage s) = d(pooled of stage s-1)
         h /= 2; w /= 2;
     }
-    return al256(stage_ws) + 2 * al256(dx_bytes);
+    return al256(stage_ws) + 2 * al256(dx_bytes) + backbone_slab_bytes(stages, channels, N, H, W, nullptr);
 }
 
 extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, const void* dpooled_last, const void* pooled_last, const float* x,
@@ -139,6 +161,11 @@ extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, cons
     }
     char* ws = (char*)workspace;
     void* dxbuf[2] = {ws + al256(stage_ws), ws + al256(stage_ws) + al256(dx_bytes)};
+    size_t slab_off[17];
+    backbone_slab_bytes(stages, channels, N, H, W, slab_off);
+    char* const slab_base = ws + al256(stage_ws) + 2 * al256(dx_bytes);
+    HybSlabInfo pending[4];
+    int npending = 0;
     const void* dp = dpooled_last;
     for (int s = stages - 1; s >= 0; --s) {
         const float* const* P = params + (size_t)s * 2;          // weight, gamma
@@ -147,11 +174,15 @@ extern "C" int hyb_backbone_bwd(int dtype, int stages, const int* channels, cons
         const int Ci = channels[s], Co = channels[s + 1];
         void* dx = s == 0 ? nullptr : dxbuf[s & 1];
         const void* pooled = s + 1 < stages ? saved[(size_t)(s + 1) * 5 + 1] : pooled_last;      // a stage's output is the next stage's saved input
-        HYB_TRY(hyb_convstage_bwd(dtype, s == 0, dp, s == 0 ? (const void*)x : S[1], S[0], pooled, P[0], P[1], (const float*)S[2], (const float*)S[3],
-                                  training, N, hs[s], wsz[s], Ci, s == 0 ? 0 : padc(Ci), Co, padc(Co), dx, G[0], G[1], G[2], S[4], ws, al256(stage_ws),
-                                  stream));
+        const bool can_defer = s > 0 && slab_off[s] != (size_t)-1;
+        HybSlabInfo info{};
+        HYB_TRY(hyb_convstage_bwd_impl(dtype, s == 0, dp, s == 0 ? (const void*)x : S[1], S[0], pooled, P[0], P[1], (const float*)S[2], (const float*)S[3],
+                                       training, N, hs[s], wsz[s], Ci, s == 0 ? 0 : padc(Ci), Co, padc(Co), dx, G[0], G[1], G[2], S[4], ws, al256(stage_ws),
+                                       stream, can_defer ? slab_base + slab_off[s] : nullptr, can_defer ? &info : nullptr));
+        if (info.S > 0) pending[npending++] = info;
         dp = dx;
     }
+    if (npending > 0) HYB_TRY(hyb_wgrad_reduce_multi(npending, pending, (hipStream_t)stream));
     return 0;
 }
 

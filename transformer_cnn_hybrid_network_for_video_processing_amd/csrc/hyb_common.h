@@ -71,6 +71,10 @@ struct HybDwRider { const float* part; float* out0; float* out1; int rows; long 
 struct HybEncTail { const void* f; const void* x1; float* st2; const float* gamma; const float* beta; float eps, out_scale, p_drop; unsigned long long seed; };
 struct HybEncBwdTail { const void* f; const float* stats; const float* gamma; void* dx; void* dskip; float* ln_part; int ln_rows; float out_scale, p_drop; unsigned long long seed; };
 
+// partial weight-gradient slabs a contraction kernel left behind for a LATER fixed-order sum (hyb_wgrad_reduce_multi, conv_wgrad.hip):
+// dW[co][ci][tap] = sum_s slab[s][(co * 9 + tap) * Cip + ci]; S = 0: nothing deferred (the gradient is already in dW)
+struct HybSlabInfo { const float* slab; float* dw; int S, Co, Ci, Cip; long long per_slab; };
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };

@@ -47,7 +47,7 @@ int hyb_stage1_bwd(int dtype, const void* dpooled, const float* x, const float* 
                    float* dbeta, const void* packed_in, void* workspace, const void* route, hipStream_t st);
 int hyb_conv3x3_wgrad_fused(int dtype, const void* x, const void* y, const void* dp, const float* ss, const float* mi, const float* gamma,
                             const float* sums, int training, long long count, void* dyraw_out, long long dyraw_blk, float* dw, int N, int H, int W,
-                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st);
+                            int Ci, int Cip, int Co, int Cop, void* workspace, size_t workspace_bytes, hipStream_t st, HybSlabInfo* defer);
 int hyb_wgrad_v2_supported(int dtype, int W, int Cip, int Cop);
 int hyb_conv_dgrad_planar_ok(int dtype, int W, int Cin_p, int Cout_p);
 int hyb_conv3x3_planar_in(const void* x, const void* wp, void* y, int N, int H, int W, int Cin_p, int Cout_p, hipStream_t st);
@@ -169,10 +169,24 @@ extern "C" size_t hyb_convstage_bwd_workspace(int dtype, int first, int N, int H
     return b;
 }
 
+int hyb_convstage_bwd_impl(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const void* pooled, const float* weight,
+                           const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
+                           int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
+                           const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream, void* slab_ws, HybSlabInfo* defer);
 extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const void* pooled, const float* weight,
                                  const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
                                  int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
                                  const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream) {
+    return hyb_convstage_bwd_impl(dtype, first, dpooled, x, y_raw, pooled, weight, gamma, scale_shift, mean_invstd, training, N, H, W, Ci, Cip, Co, Cop, dx,
+                                  dweight, dgamma, dbeta, packed_bwd, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+// slab_ws + defer (hyb_backbone_bwd): the weight-gradient slabs go to the caller's buffer, which outlives this call, and their fixed-order sum
+// is left to the caller (*defer describes it; S = 0 when this stage's kernel path summed them itself)
+int hyb_convstage_bwd_impl(int dtype, int first, const void* dpooled, const void* x, const void* y_raw, const void* pooled, const float* weight,
+                           const float* gamma, const float* scale_shift, const float* mean_invstd, int training, int N, int H, int W,
+                           int Ci, int Cip, int Co, int Cop, void* dx, float* dweight, float* dgamma, float* dbeta,
+                           const void* packed_bwd, void* workspace, size_t workspace_bytes, void* stream, void* slab_ws, HybSlabInfo* defer) {
+    if (defer) defer->S = 0;
     HYB_CHECK_ARG(dpooled && x && (first || y_raw) && weight && gamma && scale_shift && mean_invstd && dweight && workspace);
     HYB_CHECK_ARG(dtype == HYB_F32 || dtype == HYB_BF16);
     HYB_CHECK_ARG(first || dx);
@@ -188,7 +202,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     void* dyraw = ws;                            ws += align256((size_t)N * H * W * Cop * es);
     void* wpd = nullptr;
     if (!first) { wpd = ws;                      ws += align256((size_t)Cip * 9 * Cop * es); }
-    void* slabs = ws;
+    void* slabs = (slab_ws && defer) ? slab_ws : (void*)ws;
     const size_t slab_bytes = hyb_conv3x3_wgrad_workspace(first, N, H, W, Cip, Cop);
     const long long count = (long long)N * H * W;
     HYB_TRY(hyb_bn_relu_pool_bwd_reduce(dtype, dpooled, y_raw, pooled, scale_shift, mean_invstd, sums, sum_part, dgamma, dbeta, N, H, W, Co, Cop, stream));
@@ -200,7 +214,7 @@ extern "C" int hyb_convstage_bwd(int dtype, int first, const void* dpooled, cons
     const bool planar = planar_env && !first && Cop >= 64 && hyb_wgrad_v2_supported(dtype, W, Cip, Cop) && hyb_conv_dgrad_planar_ok(dtype, W, Cop, Cip);
     const long long dyraw_blk = planar ? (long long)N * H * W * 32 : 0;
     HYB_TRY(hyb_conv3x3_wgrad_fused(dtype, x, y_raw, dpooled, scale_shift, mean_invstd, gamma, sums, training, count, dyraw, dyraw_blk, dweight, N, H,
-                                    W, Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream));
+                                    W, Ci, Cip, Co, Cop, slabs, slab_bytes, (hipStream_t)stream, (slab_ws && defer) ? defer : nullptr));
     if (!first) {
         // dgrad = conv3x3 of the dense output gradient with the transposed, tap-flipped weights
         const void* wd = packed_bwd;
