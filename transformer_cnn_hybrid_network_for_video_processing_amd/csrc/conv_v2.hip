@@ -351,6 +351,232 @@ __global__ __launch_bounds__(CB * PGR * PGC * 64, CB * PGR * PGC == 4 ? 2 : 1) v
     }
 }
 
+// ---- 32 input channels (one channel block per tile): the weights live in REGISTERS ------------------------------------------------------
+// conv3x3_v2_kernel synchronises once per (tap, channel block) step -- the price of streaming weight slices through an LDS ring.  With
+// Cip = 32 a step is only MT x NT = 14 MFMAs per wave (224 matrix-pipe cycles) and the barrier, the counted wait and the ring traffic cost as
+// much as the arithmetic: stage 2's forward conv (32 -> 64 channels, 308 MB) ran at 3.6 TB/s, memory-bound on paper.  Here a wave keeps all
+// nine taps' fragments of its 32 output channels (72 registers) for the whole kernel, the halo images are a ring of THREE filled two tiles
+// ahead by LDS-DMA, and a tile costs ONE counted wait + ONE barrier.  Same tiles, fragment layout, swizzle, epilogue and statistics order
+// per tile as conv3x3_v2_kernel<2, CB, PGR, PGC, .>; the per-lane statistics are folded across lanes once, at the end.
+template <int CB, int PGR, int PGC, bool STATS>
+__global__ __launch_bounds__(CB * PGR * PGC * 64, 2) void conv3x3_k32_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wp, bf16* __restrict__ y,
+                                                                            float* __restrict__ stats, int N, int H, int W, int Cip, int Cop, int tilesX,
+                                                                            int tilesY, int numTiles, int stat_rows, int xpix, long long xblk) {
+    constexpr int NT = 2, HBN = 3;
+    using G = V2Geom<NT, CB, PGR, PGC, 3>;
+    constexpr int MT = G::MT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, HT = G::HT, NHW = G::NHW, CBW = G::CBW, PG = G::PG, NW = G::NW,
+                  NTHR = NW * 64;
+    static_assert(NW == 4, "two four-wave workgroups per CU");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* const hbuf = reinterpret_cast<bf16*>(smem_raw);                       // [3][HBUF]
+    float* const wgstat = reinterpret_cast<float*>(hbuf + HBN * G::HBUF);       // [NW waves][2][NT*16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % CB, pg = wave / CB;
+    const int prow = pg / PGC, pstrip = pg % PGC;
+    const int p = lane & 15, q = lane >> 4, py = p >> 2, px = p & 3;
+    const int co_wg = blockIdx.y * CBW;
+    const int co_base = co_wg + cb * (NT * 16);
+    const long long wrow = (long long)9 * Cip;
+    (void)xblk;
+
+    // the wave's weights: row (t, p) of the MFMA tile holds channel (t >> 1) * 32 + (p >> 2) * 8 + (t & 1) * 4 + (p & 3) (conv3x3_v2_kernel)
+    Frag<bf16> aw[9][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16* row = wp + (long long)(co_base + (t >> 1) * 32 + (p >> 2) * 8 + (t & 1) * 4 + (p & 3)) * wrow + 8 * q;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) frag_load(aw[tap][t], row + tap * 32);
+    }
+    unsigned hoff[HT];
+    int hyx[HT];
+#pragma unroll
+    for (int k = 0; k < HT; ++k) {
+        int wi = k * NW + wave;
+        if (wi > NHW - 1) wi = NHW - 1;
+        const int u = wi * 64 + lane, hp = u >> 2, sp = u & 3;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int s = sp ^ ((hy & 1) << 1);
+        hoff[k] = (unsigned)(((hy * W + hx) * xpix + s * 8) * 2);
+        hyx[k] = hp < HP ? ((hy << 20) | (hx << 4) | s) : (0x7ff << 20);
+    }
+    const int lane_el = ((prow * 4 + py) * HW_ + pstrip * 28 + px) * 32;
+    struct Tl { int n, ty0, tx0; };
+    auto decode = [&](int tile) {
+        Tl b;
+        b.n = tile / (tilesX * tilesY);
+        const int trem = tile - b.n * (tilesX * tilesY);
+        b.ty0 = (trem / tilesX) * TH;
+        b.tx0 = (trem % tilesX) * TW;
+        return b;
+    };
+    auto halo_dma = [&](const Tl& b, bf16* hb) {
+        const long long base = ((long long)(b.n * H + b.ty0 - 1) * W + (b.tx0 - 1)) * xpix;
+        const __amdgpu_buffer_rsrc_t rs = hyb_rsrc((x + base), V2_RECORDS);
+#pragma unroll
+        for (int k = 0; k < HT; ++k) {
+            const int hy = hyx[k] >> 20, hx = (hyx[k] >> 4) & 0xffff;
+            const int gy = b.ty0 - 1 + hy, gx = b.tx0 - 1 + hx;
+            const bool valid = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+            int wi = k * NW + wave;
+            if (wi > NHW - 1) wi = NHW - 1;
+            dma16(rs, valid ? hoff[k] : V2_OOB, 0, hb + wi * 512);
+        }
+    };
+    auto bptr_of = [&](const bf16* hb, int tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int sw = ((py + kh) & 1) << 1;
+        return hb + lane_el + (kh * HW_ + kw) * 32 + ((q ^ sw) << 3);
+    };
+
+    const int tchunk = (numTiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = blockIdx.x * tchunk;
+    const int tile_end = tile0 + tchunk < numTiles ? tile0 + tchunk : numTiles;
+    const int ntiles = tile_end - tile0;
+    auto tl = [&](int i) { return decode(tile0 + (i < ntiles ? i : ntiles - 1)); };
+    constexpr int NS = MT * ((NT + 1) / 2);
+
+    halo_dma(tl(0), hbuf);
+    halo_dma(tl(1), hbuf + G::HBUF);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    Frag<bf16> bfr[MT];
+    {
+        const bf16* bp = bptr_of(hbuf, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) frag_load(bfr[m], bp + m * 128);
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[t][r] = 0.f; s2[t][r] = 0.f; }
+
+    int hsel = 0;
+    bool prev_full = false;
+    for (int it = 0; it < ntiles; ++it) {
+        const Tl cur = tl(it);
+        const int h1 = hsel + 1 >= HBN ? 0 : hsel + 1, h2 = h1 + 1 >= HBN ? 0 : h1 + 1;
+        const bf16* hb_cur = hbuf + hsel * G::HBUF;
+        const bf16* hb_nxt = hbuf + h1 * G::HBUF;
+        halo_dma(tl(it + 2), hbuf + h2 * G::HBUF);            // two tiles ahead; its image was tile it - 1's: every wave left it at the last barrier
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16* bp = bptr_of(tap == 8 ? hb_nxt : hb_cur, (tap + 1) % 9);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = mma32(aw[tap][t], bfr[m], acc[m][t]);
+                frag_load(bfr[m], bp + m * 128);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+            }
+        }
+        // ---- epilogue (conv3x3_v2_kernel's): the lane holds 8 consecutive channels of one pixel per patch
+        const int n = cur.n, ty0 = cur.ty0, tx0 = cur.tx0;
+        const bool full = (ty0 + TH <= H) && (tx0 + TW <= W);
+        const int gy = ty0 + prow * 4 + py;
+        auto emit = [&](auto FULL_) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(FULL_)::value;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gx = tx0 + pstrip * 28 + m * 4 + px;
+                const bool valid = FULL || ((gy < H) && (gx < W));
+                if (valid) {
+                    bf16* dst = y + ((long long)(n * H + gy) * W + gx) * Cop + co_base + q * 8;
+                    Vec8<bf16> v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v.set(j, acc[m][j >> 2][j & 3]);
+                    v.store(dst);
+                    if (STATS) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = acc[m][t][r];
+                                s1[t][r] += a;
+                                s2[t][r] = fmaf(a, a, s2[t][r]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        // the next tile's halo (issued one iteration ago) must have landed: in issue order the outstanding operations are [this wave's DMA pieces of
+        // iteration it - 1] [its NS stores, if that tile was full] [HT pieces of this iteration] [NS stores]: leave the last three groups in flight
+        if (full) {
+            emit(std::true_type{});
+            if (prev_full) wait_vmcnt<HT + 2 * NS>(); else wait_vmcnt<HT + NS>();
+        } else {
+            emit(std::false_type{});         // edge tile: the store count depends on the lane masks, so drain
+            wait_vmcnt<0>();
+        }
+        prev_full = full;
+        __builtin_amdgcn_s_barrier();
+        hsel = h1;
+    }
+    wait_vmcnt<0>();                 // the run-ahead DMA must not outlive the workgroup
+    if (STATS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = row16_sum(s1[t][r]), b = row16_sum(s2[t][r]);
+                if (p == 0) {
+                    const int cl = (t >> 1) * 32 + q * 8 + (t & 1) * 4 + r;
+                    wgstat[(wave * 2 + 0) * (NT * 16) + cl] = a;
+                    wgstat[(wave * 2 + 1) * (NT * 16) + cl] = b;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * CBW; i += NTHR) {
+            const int which = i / CBW, cl = i % CBW;
+            const int cbi = cl / (NT * 16), c16 = cl % (NT * 16);
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) a += wgstat[((g * CB + cbi) * 2 + which) * (NT * 16) + c16];     // wave = pg*CB + cb
+            stats[((long long)blockIdx.x * 2 + which) * Cop + co_wg + cl] = a;
+            for (int rrow = blockIdx.x + gridDim.x; rrow < stat_rows; rrow += gridDim.x) stats[((long long)rrow * 2 + which) * Cop + co_wg + cl] = 0.f;
+        }
+    }
+}
+
+template <int CB, int PGR, int PGC>
+int launch_k32(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st, int xpix,
+               long long xblk) {
+    using G = V2Geom<2, CB, PGR, PGC, 3>;
+    constexpr size_t LDS = (size_t)3 * G::HBUF * 2 + G::STAT_FLOATS * 4;
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    const int tilesX = hyb_cdiv(W, G::TW), tilesY = hyb_cdiv(H, G::TH);
+    const long long numTiles = (long long)N * tilesX * tilesY;
+    int gx = (int)(numTiles < 512 ? numTiles : 512);
+    if (part && gx > stat_rows) gx = stat_rows;
+    if (gx < 1) gx = 1;
+    gx = hyb_cdiv(numTiles, hyb_cdiv(numTiles, gx));
+    const dim3 grid(gx, Cop / G::CBW);
+    static HybAttrOnce once_stats, once_plain;
+    if (int e = hyb_set_lds_attr(once_stats, (const void*)conv3x3_k32_kernel<CB, PGR, PGC, true>, (int)LDS)) return e;
+    if (int e = hyb_set_lds_attr(once_plain, (const void*)conv3x3_k32_kernel<CB, PGR, PGC, false>, (int)LDS)) return e;
+    if (part)
+        hipLaunchKernelGGL((conv3x3_k32_kernel<CB, PGR, PGC, true>), grid, dim3(256), LDS, st, x, wp, y, part, N, H, W, Cip, Cop, tilesX, tilesY, (int)numTiles,
+                           stat_rows, xpix, xblk);
+    else
+        hipLaunchKernelGGL((conv3x3_k32_kernel<CB, PGR, PGC, false>), grid, dim3(256), LDS, st, x, wp, y, (float*)nullptr, N, H, W, Cip, Cop, tilesX, tilesY,
+                           (int)numTiles, 0, xpix, xblk);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NT, int CB, int PGR, int PGC, int R>
 int launch_v2(const bf16* x, const bf16* wp, bf16* y, float* part, int N, int H, int W, int Cip, int Cop, int stat_rows, hipStream_t st, int xpix,
               long long xblk) {
@@ -403,6 +629,13 @@ int hyb_conv_v2(const void* x, const void* wp, void* y, float* part, int N, int 
     // Cop <= 128; 256-channel blocks need the whole CU's LDS for a deep weight ring.  HYB_V2_NW=4|8 forces one family.
     static const int nw_env = getenv("HYB_V2_NW") ? atoi(getenv("HYB_V2_NW")) : 0;
     const int nw = nw_env ? nw_env : (Cop % 256 == 0 ? 8 : 4);
+    static const int k32_env = getenv("HYB_CONV_K32") ? atoi(getenv("HYB_CONV_K32")) : 1;      // (=0: A/B, the ring kernel for 32 input channels too)
+    if (k32_env && nw == 4 && Cip == 32 && Cop % 64 == 0) {
+        // one channel block per tile: weights in registers, one barrier per tile (conv3x3_k32_kernel)
+        return v2_cost(N, H, W, 8, 28, Cop / 64) <= v2_cost(N, H, W, 4, 56, Cop / 64)
+                   ? launch_k32<2, 2, 1>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st, xpix, xblk)
+                   : launch_k32<2, 1, 2>(xb, wb, yb, part, N, H, W, Cip, Cop, stat_rows, st, xpix, xblk);
+    }
     if (nw == 4) {
         if (Cop % 256 == 0) return V2(4, 4, 1, 1, 3);
         if (Cop % 128 == 0) return v2_cost(N, H, W, 8, 28, Cop / 128) <= v2_cost(N, H, W, 4, 56, Cop / 128) ? V2(4, 2, 2, 1, 4) : V2(4, 2, 1, 2, 4);
