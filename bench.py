@@ -524,10 +524,10 @@ def fct_leg(dev, reps=5, frames=16, size=224):
     mha = [k for k in ept.totals if k[0] == "hyb_fct_mha_bwd"]
     if mha:
         (_, (N_, L_, C_, heads_), _), _ = max(((k, v) for k, v in ept.totals.items() if k[0] == "hyb_fct_mha_bwd"), key=lambda kv: kv[1][1])
-        kr = hooked_kernel_roofline(5, int(L_), int(heads_), 4.0 * 2 * N_ * L_ * L_ * C_ / 2, "flash_bwd4_dkv_kernel", train_pass)
+        kr = hooked_kernel_roofline(5, int(L_), int(heads_), 8.0 * N_ * L_ * L_ * C_, "flash_bwd4_dkv_kernel", train_pass)
         if kr:
             kr["what"] = (f"dK / dV kernel of FCT's attention backward, N={N_} L={L_} C={C_} heads={heads_}: recomputes S = QK^T, dP = dO V^T and forms "
-                          "dV = P^T dO, dK = dS^T Q -- 4 L^2 C multiply-adds per image")
+                          "dV = P^T dO, dK = dS^T Q -- 8 L^2 C FLOP per image")
             res["kernel_roofline"] = kr
     from oracle import fct_ref as F
     cores = host_cores()
