@@ -59,7 +59,9 @@ def build(force=False, verbose=False, jobs=8):
         links.append((out, objs))
     _drain(procs, 0)
     for out, objs in links:
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        # -z defs: a kernel whose host stub was not emitted (a target-checked builtin inside a template, rejected silently in the host pass)
+        # must fail here, not at dlopen on the GPU box
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", out] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode())

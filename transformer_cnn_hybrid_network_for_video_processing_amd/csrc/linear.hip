@@ -690,6 +690,8 @@ __global__ __launch_bounds__(256) void gemm_nt_tall_kernel(GemmArgs args, int ti
     }
 }
 
+#include "gemm_tall_lds.h"
+
 // fp32 master weight W[N][K] -> T copy Wc[N][K] and T transpose Wt[K][N] (one 32x32 tile per block, grouped over blockIdx.z)
 struct ConvertArgs {
     const float* W[18];
@@ -898,7 +900,8 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
         const ConvGather none{};
         HybProfileHook* hook = hyb_find_hook(4, No, R);
         if (hook) hipEventRecord(hook->ev0, st);
-        if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
+        if (gt_lds_ok(a, false)) { const int rc = gt_launch<false>(a, none, st); if (rc) return rc; }
+        else if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         if (hook) hipEventRecord(hook->ev1, st);
@@ -973,7 +976,8 @@ int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, f
     if (blocks > 0x7fffffff) return HYB_E_ARG;
     HybProfileHook* hook = hyb_find_hook(4, Co, Kp);          // measurement hook (hyb_profile_set): kernel 4 = the tall GEMM, keyed by (columns, K)
     if (hook) hipEventRecord(hook->ev0, st);
-    if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
+    if (Ci >= 4 && gt_lds_ok(a, true)) { const int rc = gt_launch<true>(a, cg, st); if (rc) return rc; }
+    else if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     if (hook) hipEventRecord(hook->ev1, st);
