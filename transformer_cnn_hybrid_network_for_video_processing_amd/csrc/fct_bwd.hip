@@ -568,6 +568,9 @@ int dispatch_cpl(int C, int& LPP, F&& f) {
 // Internal + used by fct MHA backward: out[Nn][K] (+)= dy^T x over P pixel rows, through SLICE_ROWS-row partial slabs in `ws`
 // Slice length of the direct kernel: enough slices that (n groups) x (k groups) x slices is about 2048 workgroups -- the big feature
 // maps (800 k pixels) have 8 .. 16 channels, i.e. ONE (n, k) group: with 4096-row slices that was 196 workgroups on 256 CUs.
+namespace {
+#include "wgrad_lds.h"
+}
 static void direct_geometry(long long P, int Nn, int K, int& ntl, int& ktl, int& rows, int& S) {
     ntl = Nn <= 16 ? 1 : 2;
     ktl = K <= 32 ? 2 : K <= 64 ? 4 : 8;
@@ -582,7 +585,9 @@ static void direct_geometry(long long P, int Nn, int K, int& ntl, int& ktl, int&
 size_t hyb_sliced_wgrad_workspace(long long P, int Nn, int K) {
     int ntl, ktl, rows, S;
     direct_geometry(P, Nn, K, ntl, ktl, rows, S);
-    const int S1 = hyb_cdiv(P, SLICE_ROWS);                      // (first-generation kernel, HYB_FCT_WGRAD_V1)
+    int S1 = hyb_cdiv(P, SLICE_ROWS);                            // (first-generation kernel, HYB_FCT_WGRAD_V1)
+    WlPlan pl;
+    if (wl_plan(pl, P, Nn, K, 4, 4, nullptr, nullptr, nullptr) && pl.S > S1) S1 = pl.S;      // (wgrad_lds_kernel's slices)
     return al256((size_t)(S > S1 ? S : S1) * Nn * K * 4);
 }
 template <int NTL, int KTL>
@@ -603,7 +608,11 @@ int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, floa
     int ntl, ktl, rows, S;
     direct_geometry(P, Nn, K, ntl, ktl, rows, S);
     float* cpart = colsum ? (float*)cws : nullptr;
-    if (legacy && !geo) {
+    WlPlan pl;
+    if (wl_plan(pl, P, Nn, K, lddy, ldx, dy, x, geo)) {
+        S = pl.S;
+        wl_launch(pl, dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, st, geo);
+    } else if (legacy && !geo) {
         S = hyb_cdiv(P, SLICE_ROWS);
         const int tk = hyb_cdiv(K, 64), tn = hyb_cdiv(Nn, 64);
         hipLaunchKernelGGL(sliced_wgrad_kernel, dim3(tk * tn, S), dim3(256), 0, st, dy, lddy, x, ldx, (float*)ws, P, Nn, K, tk, SLICE_ROWS);
