@@ -571,7 +571,7 @@ def enc32k_leg(dev, reps=5, frames=16):
     res = {"value": frames / ms * 1e3, "unit": "frames/s", "ms_per_pass": ms, "dtype": "f32",
            "workload": f"Encoder_32K training pass (forward + backward, train mode), frames [{frames},3,256,256] -> tokens [{frames},8,4096]; 72 GFLOP per frame",
            "tflops": 72.0 * frames / ms, "roofline": entry_point_roofline(ept.totals, 2)}
-    # the heaviest KERNEL by itself: the implicit-GEMM input gradient of the heaviest stride-1 convolution (gemm_nt_tall_kernel)
+    # the heaviest KERNEL by itself: the implicit-GEMM input gradient of the heaviest stride-1 convolution (gemm_nt_lds_kernel)
     convs = [(k, v) for k, v in ept.totals.items() if k[0] == "hyb_conv2d_bwd" and k[2] and k[1][6] == 1 and k[1][5] > 1]
     if convs:
         (_, key, _), _ = max(convs, key=lambda kv: kv[1][1])
@@ -584,7 +584,8 @@ def enc32k_leg(dev, reps=5, frames=16):
         per_img = Ho * Wo * ((k_ * k_ * Ci_ + 7) // 8 * 8 + Co8) * 4
         nb = max(1, min(N_, (512 << 20) // per_img))
         last = N_ - nb * ((N_ - 1) // nb)
-        kr = hooked_kernel_roofline(4, int(Ci_), int(Kp), 2.0 * last * H_ * W_ * Ci_ * Kp, "gemm_nt_tall_kernel<4, true>", train_pass)
+        kr = hooked_kernel_roofline(4, int(Ci_), int(Kp), 2.0 * last * H_ * W_ * Ci_ * Kp,
+                                    "gemm_nt_lds_kernel<%d, %d, true>" % ((128, 2) if Ci_ > 64 else (64, 3)) if Ci_ >= 64 else "gemm_nt_tall_kernel<4, true>", train_pass)
         if kr:
             kr["what"] = (f"input gradient of the {k_}x{k_} convolution {Ci_} -> {Co_} on {last} x {H_}x{W_} pixels (the last image chunk of {N_}) as an "
                           f"implicit GEMM: rows = input pixels, columns = {Ci_}, K = {Kp}")

@@ -63,7 +63,7 @@ int hyb_pad_channels(int c);
  *                variant) or the first-generation conv3x3_nhwc_kernel -- (a = Cip, b = Cop as passed; forward and dgrad launches)
  *   kernel_id 2: the weight-gradient contraction kernel -- wgrad_v3_kernel / wgrad_v2_kernel or the first-generation conv3x3_wgrad_kernel --
  *                (a = Cip, b = Cop)
- *   kernel_id 4: gemm_nt_tall_kernel, the fp32 pixel-side GEMM behind hyb_conv2d_* / hyb_fct_conv_* (a = output columns, b = K as launched)
+ *   kernel_id 4: gemm_nt_lds_kernel / gemm_nt_tall_kernel (fewer than 64 columns), the fp32 pixel-side GEMM behind hyb_conv2d_* / hyb_fct_conv_* (a = output columns, b = K as launched)
  *   kernel_id 5: flash_bwd4_dkv_kernel, the dK / dV kernel of FCT's attention backward over narrow heads (a = tokens L, b = heads)
  * slot in [0, 16).  hyb_profile_clear() removes all hooks.  The hook table is never touched unless a hook is set, and it is
  * not thread-safe (measurement runs only). */

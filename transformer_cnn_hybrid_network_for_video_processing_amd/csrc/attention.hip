@@ -31,6 +31,7 @@ struct AttnDims {
     int nt;      // 16-token tiles per sequence = waves per workgroup
     int DT;      // 16-feature tiles per head
     int ldi;     // LDS image row stride in elements
+    int ldp;     // backward, several tiles: row stride of the P / dS images [query][key]
     int ld_qkv;  // token row stride (elements) of q, k, v and dq, dk, dv (D, or 3D when they are packed as [M][3D])
     int ld_o;    // token row stride of out / dout
     int ppw;     // problems per workgroup: > 1 only for single-tile sequences (S <= 16), where every wave takes its own (clip, head)
@@ -270,6 +271,10 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
     T* Qimg = Kimg + rows * d.ldi;
     T* Gimg = Qimg + rows * d.ldi;                             // dO
     float* delta = reinterpret_cast<float*>(Gimg + rows * d.ldi);   // [rows]
+    // several tiles: phase A leaves the (dropped) probabilities and the score gradients of its query tile here, [query][key]; phase B reads
+    // them back transposed instead of recomputing both products, the exponentials and the row statistics per (key tile, query tile) pair
+    T* Pimg = reinterpret_cast<T*>(delta + rows);
+    T* Simg = Pimg + rows * d.ldp;
     const int p = lane & 15, g = lane >> 4;
     const long long boff = (long long)b * d.S * d.ld_qkv + h * d.dh;
     const T* qb = q + boff;
@@ -361,22 +366,31 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                         dpT[kt] = mma32(av, bg, dpT[kt]);
                     }
                 }
+                float pd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
                     float sv = pT[kt][r] * scale;
                     if (mrow && key < d.S && mrow[key] == 0.f) sv = -1e9f;
                     float pv = (qok && key < d.S) ? __expf(sv - mx) * inv : 0.f;
-                    float dp = dpT[kt][r];
-                    if (p_drop > 0.f && qok && key < d.S)
-                        dp *= dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
+                    float dp = dpT[kt][r], mult = 1.f;
+                    if (p_drop > 0.f && qok && key < d.S) {
+                        mult = dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
+                        dp *= mult;
+                    }
                     pT[kt][r] = pv; dpT[kt][r] = dp;
                     dl += pv * dp;
+                    if (!SINGLE) pd[r] = pv * mult;
+                }
+                if (!SINGLE) {                                 // P (with the dropout mask applied) of this (query row, 4 keys): for dV in phase B
+                    Frag16<T> pf;
+                    acc_to_frag(pf, pd);
+                    *reinterpret_cast<Frag16<T>*>(Pimg + (qt * 16 + p) * d.ldp + kt * 16 + 4 * g) = pf;
                 }
             }
         }
         dl = quad_lane_sum(dl);
-        if (g == 0) delta[qt * 16 + p] = dl;
+        if (SINGLE && g == 0) delta[qt * 16 + p] = dl;
         Frag16<T> dsT[NTC];
 #pragma unroll
         for (int kt = 0; kt < NTC; ++kt)
@@ -385,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[r] = pT[kt][r] * (dpT[kt][r] - dl) * scale;
                 acc_to_frag(dsT[kt], x);
+                if (!SINGLE) *reinterpret_cast<Frag16<T>*>(Simg + (qt * 16 + p) * d.ldp + kt * 16 + 4 * g) = dsT[kt];      // dS: for dK in phase B
             }
 #pragma unroll
         for (int dt = 0; dt < MAXDT; ++dt)
@@ -404,63 +419,23 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                 }
             }
     }
-    __syncthreads();                                           // delta of every query tile is in LDS
+    __syncthreads();                                           // delta (one tile) / the P and dS images (several) are complete
     // ---------------- phase B: one KEY tile at a time, all query tiles (normal orientation: rows = queries, column = key p)
-    for (int kt = wave; kt < d.nt; kt += nw) {
-        const int key = kt * 16 + p;
-        const bool kok = key < d.S;
-        f32x4 dkT[SINGLE ? 1 : MAXDT], dvT[SINGLE ? 1 : MAXDT];
-#pragma unroll
-        for (int dt = 0; dt < (SINGLE ? 1 : MAXDT); ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if constexpr (!SINGLE && HOIST) {
+    if constexpr (SINGLE) {
+        for (int kt = wave; kt < d.nt; kt += nw) {
+            const int key = kt * 16 + p;
+            const bool kok = key < d.S;
+            f32x4 sN = f32x4{0.f, 0.f, 0.f, 0.f}, dpN = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 if (s < ks) {
-                    const int f0 = s * 32 + 8 * g;
-                    row_frag(fk[s], kb, d.ld_qkv, key, d.S, f0, d.dh);
-                    row_frag(fv[s], vb, d.ld_qkv, key, d.S, f0, d.dh);
+                    sN = mma32(fq[s], fk[s], sN);
+                    dpN = mma32(fg[s], fv[s], dpN);
                 }
-        }
-        for (int qt = 0; qt < d.nt; ++qt) {
-            f32x4 sN = f32x4{0.f, 0.f, 0.f, 0.f}, dpN = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (SINGLE) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s < ks) {
-                        sN = mma32(fq[s], fk[s], sN);
-                        dpN = mma32(fg[s], fv[s], dpN);
-                    }
-            } else if constexpr (HOIST) {
-                Frag<T> aq[4], ag[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s < ks) {
-                        const int f0 = s * 32 + 8 * g;
-                        row_frag(aq[s], qb, d.ld_qkv, qt * 16 + p, d.S, f0, d.dh);
-                        row_frag(ag[s], gb, d.ld_o, qt * 16 + p, d.S, f0, d.dh);
-                    }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s < ks) {
-                        sN = mma32(aq[s], fk[s], sN);
-                        dpN = mma32(ag[s], fv[s], dpN);
-                    }
-            } else {
-                for (int s = 0; s < ks; ++s) {
-                    Frag<T> aq, bk, ag, bv;
-                    const int f0 = s * 32 + 8 * g;
-                    row_frag(aq, qb, d.ld_qkv, qt * 16 + p, d.S, f0, d.dh);
-                    row_frag(bk, kb, d.ld_qkv, key, d.S, f0, d.dh);
-                    row_frag(ag, gb, d.ld_o, qt * 16 + p, d.S, f0, d.dh);
-                    row_frag(bv, vb, d.ld_qkv, key, d.S, f0, d.dh);
-                    sN = mma32(aq, bk, sN);
-                    dpN = mma32(ag, bv, dpN);
-                }
-            }
             float ds[4], pd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int query = qt * 16 + 4 * g + r;
+                const int query = 4 * g + r;
                 const bool ok = kok && query < d.S;
                 float pv = 0.f, mult = 1.f;
                 if (ok) {
@@ -470,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                     pv = __expf(sv - st[0]) / st[1];
                     if (p_drop > 0.f) mult = dropout_mult(seed, ((unsigned long long)pidx * d.S + query) * d.S + key, p_drop, inv_keep);
                 }
-                ds[r] = pv * (dpN[r] * mult - delta[qt * 16 + 4 * g + r]) * scale;
+                ds[r] = pv * (dpN[r] * mult - delta[4 * g + r]) * scale;
                 pd[r] = pv * mult;
             }
             Frag16<T> dsF, pdF;
@@ -480,34 +455,54 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
             for (int dt = 0; dt < MAXDT; ++dt)
                 if (dt < d.DT) {
                     Frag16<T> aq, ag;
-                    tr_read(aq, Qimg, d.ldi, qt * 16, dt * 16, lane);          // Q^T[feature][query]
-                    tr_read(ag, Gimg, d.ldi, qt * 16, dt * 16, lane);          // dO^T[feature][query]
-                    if (SINGLE) {                                              // one query tile: the tile is final, store it now (no live accumulators)
-                        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                        const f32x4 tk = mma16(aq, dsF, z), tv = mma16(ag, pdF, z);      // matrix ops stay outside the divergent store branch
-                        const int f0 = dt * 16 + 4 * g;
-                        if (valid && kok && f0 < d.dh) {
-                            const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
-                            if (d.relu_out) { store4_relu(dk + o, k + o, tk); store4_relu(dv + o, v + o, tv); }
-                            else { store4(dk + o, tk); store4(dv + o, tv); }
-                        }
-                    } else {
-                        dkT[dt] = mma16(aq, dsF, dkT[dt]);
-                        dvT[dt] = mma16(ag, pdF, dvT[dt]);
+                    tr_read(aq, Qimg, d.ldi, 0, dt * 16, lane);                // Q^T[feature][query]
+                    tr_read(ag, Gimg, d.ldi, 0, dt * 16, lane);                // dO^T[feature][query]
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 tk = mma16(aq, dsF, z), tv = mma16(ag, pdF, z);          // matrix ops stay outside the divergent store branch
+                    const int f0 = dt * 16 + 4 * g;
+                    if (valid && kok && f0 < d.dh) {
+                        const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
+                        if (d.relu_out) { store4_relu(dk + o, k + o, tk); store4_relu(dv + o, v + o, tv); }
+                        else { store4(dk + o, tk); store4(dv + o, tv); }
                     }
                 }
         }
-        if (!SINGLE)
+    } else {
+        // several tiles: dK^T = Q^T dS, dV^T = dO^T P with all four operands read transposed from the LDS images -- no global loads, no
+        // exponentials and no row statistics in this phase
+        for (int kt = wave; kt < d.nt; kt += nw) {
+            const int key = kt * 16 + p;
+            const bool kok = key < d.S;
+            f32x4 dkT[MAXDT], dvT[MAXDT];
 #pragma unroll
-        for (int dt = 0; dt < MAXDT; ++dt)
-            if (dt < d.DT) {
-                const int f0 = dt * 16 + 4 * g;
-                if (valid && kok && f0 < d.dh) {
-                    const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
-                    if (d.relu_out) { store4_relu(dk + o, k + o, dkT[dt]); store4_relu(dv + o, v + o, dvT[dt]); }
-                    else { store4(dk + o, dkT[dt]); store4(dv + o, dvT[dt]); }
+            for (int dt = 0; dt < MAXDT; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int qt = 0; qt < MAXT; ++qt)
+                if (qt < d.nt) {
+                    Frag16<T> dsF, pdF;
+                    tr_read(dsF, Simg, d.ldp, qt * 16, kt * 16, lane);         // dS[query 4g + j][key p]
+                    tr_read(pdF, Pimg, d.ldp, qt * 16, kt * 16, lane);
+#pragma unroll
+                    for (int dt = 0; dt < MAXDT; ++dt)
+                        if (dt < d.DT) {
+                            Frag16<T> aq, ag;
+                            tr_read(aq, Qimg, d.ldi, qt * 16, dt * 16, lane);  // Q^T[feature][query]
+                            tr_read(ag, Gimg, d.ldi, qt * 16, dt * 16, lane);  // dO^T[feature][query]
+                            dkT[dt] = mma16(aq, dsF, dkT[dt]);
+                            dvT[dt] = mma16(ag, pdF, dvT[dt]);
+                        }
                 }
-            }
+#pragma unroll
+            for (int dt = 0; dt < MAXDT; ++dt)
+                if (dt < d.DT) {
+                    const int f0 = dt * 16 + 4 * g;
+                    if (valid && kok && f0 < d.dh) {
+                        const long long o = ((long long)(b * d.S + key)) * d.ld_qkv + h * d.dh + f0;
+                        if (d.relu_out) { store4_relu(dk + o, k + o, dkT[dt]); store4_relu(dv + o, v + o, dvT[dt]); }
+                        else { store4(dk + o, dkT[dt]); store4(dv + o, dvT[dt]); }
+                    }
+                }
+        }
     }
 }
 
@@ -521,6 +516,9 @@ inline bool attn_dims(AttnDims& d, int B, int S, int D, int H, size_t es) {
     int bytes = d.DT * 16 * (int)es;
     if ((bytes / 32) % 2 == 0) bytes += 32;
     d.ldi = bytes / (int)es;
+    int pbytes = d.nt * 16 * (int)es;
+    if ((pbytes / 32) % 2 == 0) pbytes += 32;
+    d.ldp = pbytes / (int)es;
     d.ld_qkv = D;
     d.ld_o = D;
     d.relu_out = 0;
@@ -556,7 +554,8 @@ int attn_fwd_t(const void* q, const void* k, const void* v, const float* mask, v
 template <typename T>
 int attn_bwd_t(const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout, void* dq, void* dk, void* dv,
                const AttnDims& d, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
-    const size_t lds = (size_t)d.ppw * ((size_t)3 * d.nt * 16 * d.ldi * sizeof(T) + (size_t)d.nt * 16 * sizeof(float));     // fp32, 128-wide heads, S = 64: 104 KiB
+    const size_t lds = (size_t)d.ppw * ((size_t)3 * d.nt * 16 * d.ldi * sizeof(T) + (size_t)d.nt * 16 * sizeof(float)) +
+                       (d.nt > 1 ? (size_t)2 * d.nt * 16 * d.ldp * sizeof(T) : 0);      // fp32, 128-wide heads, S = 64: 104 + 36 KiB
     const float scale = 1.0f / sqrtf((float)d.D);
     const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
     if (d.nt == 1) {
