@@ -95,6 +95,13 @@ __device__ __forceinline__ void row_frag(Frag<T>& f, const T* __restrict__ base,
     else frag_zero(f);
 }
 
+// the same fragment from a staged LDS image (rows >= S and columns >= dh of the image are zero; f0 may lie beyond the staged columns)
+template <typename T>
+__device__ __forceinline__ void img_frag(Frag<T>& f, const T* img, int ldi, int tok, int f0, int dh) {
+    if (f0 < dh) frag_load(f, img + tok * ldi + f0);
+    else frag_zero(f);
+}
+
 __device__ __forceinline__ float quad_lane_max(float v) {        // over the 4 lanes p, p+16, p+32, p+48
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -275,6 +282,9 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
     // them back transposed instead of recomputing both products, the exponentials and the row statistics per (key tile, query tile) pair
     T* Pimg = reinterpret_cast<T*>(delta + rows);
     T* Simg = Pimg + rows * d.ldp;
+    // 16-bit storage, several tiles: V is staged too and phase A takes every row fragment from the images (one global pass per operand)
+    constexpr bool VIMG = !SINGLE && sizeof(T) == 2;
+    T* Vimg = Simg + rows * d.ldp;
     const int p = lane & 15, g = lane >> 4;
     const long long boff = (long long)b * d.S * d.ld_qkv + h * d.dh;
     const T* qb = q + boff;
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         stage_image(Kimg, k, d, b, h, d.ld_qkv, pt, pn);
         stage_image(Qimg, q, d, b, h, d.ld_qkv, pt, pn);
         stage_image(Gimg, dout, d, b, h, d.ld_o, pt, pn);
+        if (VIMG) stage_image(Vimg, v, d, b, h, d.ld_qkv, pt, pn);
     }
     __syncthreads();                                           // images complete
     seed += seed_step;
@@ -315,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
             for (int s = 0; s < 4; ++s)
                 if (s < ks) {
                     const int f0 = s * 32 + 8 * g;
-                    row_frag(fq[s], qb, d.ld_qkv, query, d.S, f0, d.dh);
-                    row_frag(fg[s], gb, d.ld_o, query, d.S, f0, d.dh);
+                    img_frag(fq[s], Qimg, d.ldi, qt * 16 + p, f0, d.dh);
+                    img_frag(fg[s], Gimg, d.ldi, qt * 16 + p, f0, d.dh);
                 }
         }
 #pragma unroll
@@ -345,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
                     for (int s = 0; s < 4; ++s)
                         if (s < ks) {
                             const int f0 = s * 32 + 8 * g;
-                            row_frag(ak[s], kb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
-                            row_frag(av[s], vb, d.ld_qkv, kt * 16 + p, d.S, f0, d.dh);
+                            img_frag(ak[s], Kimg, d.ldi, kt * 16 + p, f0, d.dh);
+                            img_frag(av[s], Vimg, d.ldi, kt * 16 + p, f0, d.dh);
                         }
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -555,7 +566,8 @@ template <typename T>
 int attn_bwd_t(const void* q, const void* k, const void* v, const float* mask, const float* stats, const void* dout, void* dq, void* dk, void* dv,
                const AttnDims& d, float p_drop, unsigned long long seed, const unsigned long long* seed_inc, hipStream_t st) {
     const size_t lds = (size_t)d.ppw * ((size_t)3 * d.nt * 16 * d.ldi * sizeof(T) + (size_t)d.nt * 16 * sizeof(float)) +
-                       (d.nt > 1 ? (size_t)2 * d.nt * 16 * d.ldp * sizeof(T) : 0);      // fp32, 128-wide heads, S = 64: 104 + 36 KiB
+                       (d.nt > 1 ? (size_t)2 * d.nt * 16 * d.ldp * sizeof(T) + (sizeof(T) == 2 ? (size_t)d.nt * 16 * d.ldi * sizeof(T) : 0) : 0);
+    // (fp32, 128-wide heads, S = 64: 104 + 36 KiB; bf16, 96-wide, S = 64: 43 + 20 + 14 KiB -- two workgroups per CU)
     const float scale = 1.0f / sqrtf((float)d.D);
     const dim3 grid(hyb_cdiv((long long)d.B * d.H, d.ppw)), block((d.ppw > 1 ? d.ppw : attn_waves(d)) * 64);
     if (d.nt == 1) {
