@@ -302,6 +302,9 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         stage_image(Gimg, dout, d, b, h, d.ld_o, pt, pn);
         if (VIMG) stage_image(Vimg, v, d, b, h, d.ld_qkv, pt, pn);
     }
+    // the softmax statistics of this wave's first query tile: requested before the barrier, so the round trip rides under the staging
+    float st0_mx = 0.f, st0_l = 1.f;
+    if (wave * 16 + p < d.S) { const float* st = stats + ((long long)pidx * d.S + wave * 16 + p) * 2; st0_mx = st[0]; st0_l = st[1]; }
     __syncthreads();                                           // images complete
     seed += seed_step;
     // single-tile sequences (S <= 16): the row fragments of K, Q, V, dO are the same registers in both phases (A and B operands
@@ -317,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_kernel(const T* __restri
         const int query = qt * 16 + p;
         const bool qok = query < d.S;
         float mx = 0.f, inv = 0.f;
-        if (qok) { const float* st = stats + ((long long)pidx * d.S + query) * 2; mx = st[0]; inv = 1.f / st[1]; }
+        if (qt == wave) { mx = st0_mx; inv = qok ? 1.f / st0_l : 0.f; }
+        else if (qok) { const float* st = stats + ((long long)pidx * d.S + query) * 2; mx = st[0]; inv = 1.f / st[1]; }
         const float* mrow = mbase ? mbase + (long long)(qok ? query : 0) * d.S : nullptr;
         f32x4 pT[NTC], dpT[NTC];
         float dl = 0.f;
