@@ -36,34 +36,57 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     __shared__ float s_corr[2];
-    float step_size = a.step_size, inv_sqrt_bc2 = a.inv_sqrt_bc2;
-    if (a.step_inc) {                                          // uniform branch: every thread reaches the barrier
-        if (threadIdx.x == 0) {
-            const double t = (double)(a.step + *a.step_inc);
-            s_corr[0] = (float)(a.lr / (1.0 - pow(a.beta1d, t)));
-            s_corr[1] = (float)(1.0 / sqrt(1.0 - pow(a.beta2d, t)));
-        }
-        __syncthreads();
-        step_size = s_corr[0]; inv_sqrt_bc2 = s_corr[1];
-    }
     int ti = 0;
     for (int i = 1; i < a.count; ++i)
         if ((int)blockIdx.x >= a.chunk_begin[i]) ti = i;
     const AdamTensor t = a.t[ti];
     const long long base = (long long)(blockIdx.x - a.chunk_begin[ti]) * ADAM_CHUNK;
     const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+    constexpr int NK = ADAM_CHUNK / (256 * 4);
+    // a full, aligned chunk (all but each tensor's last): its 16 loads are issued BEFORE the bias corrections are formed (two double-
+    // precision pow() on one thread, ~2 us) -- the kernel used to start every workgroup with that, then run four load -> store rounds
+    const bool full = vec && base + ADAM_CHUNK <= t.n;
+    f32x4 p[NK], m[NK], v[NK], g[NK];
+    if (full) {
 #pragma unroll
-    for (int k = 0; k < ADAM_CHUNK / (256 * 4); ++k) {
-        const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
-        if (i >= t.n) break;
-        if (vec && i + 4 <= t.n) {
-            f32x4 p = *reinterpret_cast<f32x4*>(t.p + i), m = *reinterpret_cast<f32x4*>(t.m + i), v = *reinterpret_cast<f32x4*>(t.v + i);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
+        for (int k = 0; k < NK; ++k) {
+            const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+            p[k] = *reinterpret_cast<const f32x4*>(t.p + i); m[k] = *reinterpret_cast<const f32x4*>(t.m + i);
+            v[k] = *reinterpret_cast<const f32x4*>(t.v + i); g[k] = *reinterpret_cast<const f32x4*>(t.g + i);
+        }
+    }
+    float step_size = a.step_size, inv_sqrt_bc2 = a.inv_sqrt_bc2;
+    if (a.step_inc) {                                          // uniform branch: every thread reaches the barrier
+        if (threadIdx.x == 0) {
+            const double tt = (double)(a.step + *a.step_inc);
+            s_corr[0] = (float)(a.lr / (1.0 - pow(a.beta1d, tt)));
+            s_corr[1] = (float)(1.0 / sqrt(1.0 - pow(a.beta2d, tt)));
+        }
+        __syncthreads();
+        step_size = s_corr[0]; inv_sqrt_bc2 = s_corr[1];
+    }
+    if (full) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float pj = p[j], mj = m[j], vj = v[j]; adam_one(pj, g[j], mj, vj, a, step_size, inv_sqrt_bc2); p[j] = pj; m[j] = mj; v[j] = vj; }
-            *reinterpret_cast<f32x4*>(t.p + i) = p; *reinterpret_cast<f32x4*>(t.m + i) = m; *reinterpret_cast<f32x4*>(t.v + i) = v;
-        } else {
-            for (long long e = i; e < i + 4 && e < t.n; ++e) adam_one(t.p[e], t.g[e], t.m[e], t.v[e], a, step_size, inv_sqrt_bc2);
+        for (int k = 0; k < NK; ++k) {
+            const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float pj = p[k][j], mj = m[k][j], vj = v[k][j]; adam_one(pj, g[k][j], mj, vj, a, step_size, inv_sqrt_bc2); p[k][j] = pj; m[k][j] = mj; v[k][j] = vj; }
+            *reinterpret_cast<f32x4*>(t.p + i) = p[k]; *reinterpret_cast<f32x4*>(t.m + i) = m[k]; *reinterpret_cast<f32x4*>(t.v + i) = v[k];
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < NK; ++k) {
+            const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+            if (i >= t.n) break;
+            if (vec && i + 4 <= t.n) {
+                f32x4 pp = *reinterpret_cast<f32x4*>(t.p + i), mm = *reinterpret_cast<f32x4*>(t.m + i), vv = *reinterpret_cast<f32x4*>(t.v + i);
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(t.g + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float pj = pp[j], mj = mm[j], vj = vv[j]; adam_one(pj, gg[j], mj, vj, a, step_size, inv_sqrt_bc2); pp[j] = pj; mm[j] = mj; vv[j] = vj; }
+                *reinterpret_cast<f32x4*>(t.p + i) = pp; *reinterpret_cast<f32x4*>(t.m + i) = mm; *reinterpret_cast<f32x4*>(t.v + i) = vv;
+            } else {
+                for (long long e = i; e < i + 4 && e < t.n; ++e) adam_one(t.p[e], t.g[e], t.m[e], t.v[e], a, step_size, inv_sqrt_bc2);
+            }
         }
     }
     // Thread 0 consumed the counter's value before the barrier at the top, so its read is complete here; the ticket only orders "every
