@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_F32_PEAK_TFLOPS = 157.3
 # bf16x3: every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi), so the mode's own ceiling in useful FLOPs is a third of the bf16 peak
-MODE_PEAK = {"bf16": MFMA_BF16_PEAK_TFLOPS, "bf16x3": MFMA_BF16_PEAK_TFLOPS / 3.0, "fp32": MFMA_F32_PEAK_TFLOPS}
+# mixed: bf16 conv stages (where the dominant kernel lives) + bf16x3 temporal part
+MODE_PEAK = {"bf16": MFMA_BF16_PEAK_TFLOPS, "mixed": MFMA_BF16_PEAK_TFLOPS, "bf16x3": MFMA_BF16_PEAK_TFLOPS / 3.0, "fp32": MFMA_F32_PEAK_TFLOPS}
 HBM_PEAK_GBS = 8000.0               # HBM3E spec peak (6.29 TB/s measured copy)
 
 CFG = dict(cnn_channels=(32, 64, 128, 256), num_layers=2, num_classes=8)
@@ -51,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3", "mixed"])
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (defaults of the flags below)")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=None)
@@ -210,7 +211,7 @@ def instep_kernel_table(args, step_fn, nsteps=8):
     chans = (3,) + CFG["cnn_channels"]
     specs = []
     H = args.size // 2
-    bf16 = getattr(args, "dtype", "bf16") == "bf16"
+    bf16 = getattr(args, "dtype", "bf16") in ("bf16", "mixed")        # (mixed: the conv stages are the bf16 mode's)
     es = 2 if bf16 else 4                             # fp32 and bf16x3 store fp32 activations
     for li in range(1, 4):
         ci, co = chans[li], chans[li + 1]
@@ -484,6 +485,8 @@ def model_leg(cfgno, dtype, dev, steps, warmup, want_roofline):
                            "how": "HIP events recorded by the library around this kernel inside 4 real steps (hyb_profile_set)"}
         if dtype == "bf16x3":
             res["roofline"]["peak_note"] = "2500 / 3 TFLOP/s: three bf16 MFMAs per product in this mode"
+        if dtype == "mixed":
+            res["roofline"]["peak_note"] = "the dominant kernel belongs to the bf16 conv stages: priced against the bf16 peak"
         assert 0.0 < res["roofline"]["frac"] < 1.0, res["roofline"]       # (an events-timed-nothing hook once reported 83.6)
     if trainer is not None:
         trainer.close()
@@ -635,7 +638,7 @@ def bf16_logits_check(dev):
     with torch.no_grad():
         lr = ref(x)
     out = {}
-    for mode in ("bf16", "bf16x3", "fp32"):
+    for mode in ("bf16", "mixed", "bf16x3", "fp32"):
         m = P.TransformerCNNHybrid(compute_dtype=mode)
         m.load_state_dict(sd)
         for a in m.encoder.attention_layers:
@@ -876,8 +879,9 @@ def main():
                        "optimizer": "HybridAdamW (hyb_adamw_step, one launch)" if args.optimizer == "hybrid" else "torch.optim.AdamW(fused=True)",
                        "parallelism": f"dp{world}",
                        "train_mode": "BatchNorm batch stats, attention dropout 0.1 (reference semantics)",
-                       "logits_parity": "north_star's 1e-3 rel vs the CPU oracle is met by compute_dtype fp32 (exact fp32 MFMA) and bf16x3 (split-bf16 "
-                                        "products); bf16 mode is at bf16 rounding level -- all three measured in this run: key logits_check"},
+                       "logits_parity": "north_star's 1e-3 rel vs the CPU oracle is met by compute_dtype fp32 (exact fp32 MFMA), bf16x3 (split-bf16 "
+                                        "products) and mixed (bf16 conv stages + bf16x3 temporal part); bf16 mode is at bf16 rounding level -- all four "
+                                        "measured in this run: key logits_check"},
             "final_loss": final_loss,
             "graph_fallback": bool(graph_fallback),
         }
@@ -924,7 +928,7 @@ def main():
             torch.cuda.empty_cache()
             legs = (("config4", lambda: model_leg(4, "bf16", dev, 10, 3, True)), ("config5", lambda: model_leg(5, "bf16", dev, 10, 3, True)),
                     ("fp32", lambda: model_leg(2, "fp32", dev, 10, 3, False)), ("bf16x3", lambda: model_leg(2, "bf16x3", dev, 10, 3, True)),
-                    ("fct", lambda: fct_leg(dev)), ("enc32k", lambda: enc32k_leg(dev)), ("logits_check", lambda: bf16_logits_check(dev)),
+                    ("mixed", lambda: model_leg(2, "mixed", dev, 20, 5, True)), ("fct", lambda: fct_leg(dev)), ("enc32k", lambda: enc32k_leg(dev)), ("logits_check", lambda: bf16_logits_check(dev)),
                     ("cpu_baseline_config1", config1_cpu_baseline))
             for key, fn in legs:
                 if key == "cpu_baseline_config1" and args.no_cpu_baseline:
@@ -935,13 +939,16 @@ def main():
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
             # the headline mode (bf16, BASELINE config 2's dtype) is at bf16 rounding level; north_star's "logits within 1e-3 rel of the CPU
             # reference" is met by the bf16x3 mode: its throughput on the SAME workload, and the errors of both measured in this run
-            lc, x3 = out.get("logits_check", {}), out.get("bf16x3", {})
-            if "value" in x3 and "bf16x3" in lc:
+            lc = out.get("logits_check", {})
+            ok = [(out[m]["value"], m) for m in ("mixed", "bf16x3", "fp32") if "value" in out.get(m, {}) and lc.get(m, 1.0) <= 1e-3]
+            if ok:
+                _, best = max(ok)
                 out["value_at_north_star_tolerance"] = {
-                    "value": x3["value"], "unit": "clips/s", "dtype": "bf16x3", "ms_per_step": x3["ms_per_step"], "logits_rel_err": lc["bf16x3"],
+                    "value": out[best]["value"], "unit": "clips/s", "dtype": best, "ms_per_step": out[best]["ms_per_step"], "logits_rel_err": lc[best],
                     "tolerance": 1e-3, "headline_logits_rel_err": lc.get("bf16"),
-                    "what": "same config-2 full step in compute_dtype bf16x3 (fp32 storage, split-bf16 MFMA products): the fastest mode whose forward "
-                            "logits are within north_star's 1e-3 of the CPU oracle; the headline `value` is the bf16 mode, whose logits error is "
+                    "what": "same config-2 full step in the fastest compute_dtype whose forward logits are within north_star's 1e-3 of the CPU oracle "
+                            "(measured in this run, `logits_check`): 'mixed' = bf16 conv stages + split-bf16 (bf16x3) temporal part, 'bf16x3' = "
+                            "fp32 storage with split-bf16 MFMA products everywhere; the headline `value` is the bf16 mode, whose logits error is "
                             "`headline_logits_rel_err`"}
         print(json.dumps(out), flush=True)
     if world > 1:
