@@ -45,6 +45,11 @@ extern "C" {
 
 #define HYB_F32 0
 #define HYB_BF16 1
+/* May be OR-ed into the `dtype` of hyb_temporal_{fwd,bwd} / hyb_temporal_ce_{fwd,bwd} when dtype is HYB_F32: the last pooled map `h` (and its
+ * gradient `dh`) is bf16 although the temporal part stores and computes in fp32 -- the "mixed" mode of the host side (bf16 conv stages,
+ * fp32 / split-bf16 temporal part): the global-average-pool kernels read / write the other type, no cast launches.  Workspace / saved-size
+ * queries take the plain dtype. */
+#define HYB_H_BF16 0x100
 
 #define HYB_E_ARG (-1)      /* bad argument (null pointer, unsupported size) */
 #define HYB_E_WORKSPACE (-2) /* workspace too small */

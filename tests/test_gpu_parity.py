@@ -424,6 +424,46 @@ def _model_pair(mode, **kw):
     return ref, hip.cuda()
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["model_ops", "stage_ops"])
+def test_mixed_mode_is_the_bf16_backbone_in_front_of_the_bf16x3_temporal_part(fused):
+    """compute_dtype="mixed" composes the two modes and nothing else: its pooled map is the bf16 model's bit for bit, and its logits are the
+    bf16x3 temporal part's on that map (widened to fp32) bit for bit -- through the fused operators (HYB_H_BF16: the global-average-pool
+    kernels read bf16) and through the per-stage operators (a cast launch).  The logits then sit within 1e-3 of the oracle's where the all-bf16
+    model's do not have to (full size: tests/test_gpu_fullsize.py)."""
+    kw = dict(cnn_channels=(32, 64), d_model=64, num_heads=4, num_layers=2, hidden_dim=128)
+    torch.manual_seed(0)
+    ref = R.TransformerCNNHybridRef(**kw).eval()
+    models = {}
+    for mode in ("mixed", "bf16", "bf16x3"):
+        m = P().TransformerCNNHybrid(compute_dtype=mode, **kw)
+        m.load_state_dict(ref.state_dict())
+        m.fuse_model_ops = fused
+        models[mode] = m.cuda().eval()
+    x, _ = R.synthetic_batch(2, 4, 64, 64, seed=0)
+    with torch.no_grad():
+        lr = ref(x)
+        hm, B = models["mixed"].forward_backbone(x.cuda())
+        hb, _ = models["bf16"].forward_backbone(x.cuda())
+        assert hm.dtype == torch.bfloat16 and torch.equal(hm, hb)
+        lm = models["mixed"].forward_temporal(hm, B)
+        lx = models["bf16x3"].forward_temporal(hb.float(), B)
+        assert torch.equal(lm, lx)
+        lb = models["bf16"](x.cuda())
+    scale = lr.abs().max().item()
+    em, eb = (lm.cpu() - lr).abs().max().item() / scale, (lb.float().cpu() - lr).abs().max().item() / scale
+    print(f"\nlogits max-rel vs oracle: mixed {em:.2e}, bf16 {eb:.2e}")
+    assert em <= 1e-3 and em < eb
+    # gradients flow through the hand-over in both directions: dh arrives at the conv stages as bf16
+    m = models["mixed"].train()
+    for a in m.encoder.attention_layers:
+        a.dropoutLayer.p = 0.0
+    y = torch.tensor([1, 3]).cuda()
+    loss = P().HybridCrossEntropyLoss()(m(x.cuda()), y)
+    loss.backward()
+    for n, p_ in m.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all() and p_.grad.abs().max().item() > 0, n
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("cfg", [
     dict(B=1, T=8, H=112, W=112, kw={}),                                     # BASELINE config 1 shape, config-2 model

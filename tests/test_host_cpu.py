@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built):
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in built.protos:
         assert hasattr(dll, name), f"{name} declared in include/hybrid_hip.h but not exported"
-    assert built.query("hyb_abi_version") == 8
+    assert built.query("hyb_abi_version") == 9
     assert built.query("hyb_dtype_size", 0) == 4 and built.query("hyb_dtype_size", 1) == 2 and built.query("hyb_dtype_size", 7) == -1
     assert built.query("hyb_pad_channels", 3) == 32 and built.query("hyb_pad_channels", 64) == 64 and built.query("hyb_pad_channels", 65) == 96
 

@@ -14,6 +14,7 @@ LIB_X3_PATH = os.path.join(PKG, "libhybrid_hip_x3.so")
 # dtype codes of the C ABI (include/hybrid_hip.h) -- and HYB_F32X3, which exists on the host side only: the SAME ABI served by the second
 # build of the library (libhybrid_hip_x3.so, -DHYB_F32_X3), where HYB_F32 means "fp32 storage, products from split-bf16 MFMAs"
 HYB_F32, HYB_BF16, HYB_F32X3 = 0, 1, 2
+HYB_H_BF16 = 0x100           # flag on the dtype of hyb_temporal_*: the pooled map / its gradient are bf16 (include/hybrid_hip.h)
 
 _CTYPES = {
     "int": ctypes.c_int,
@@ -99,16 +100,20 @@ class _Mux(_Lib):
         super().__init__(LIB_PATH)
         self.x3 = _Lib(LIB_X3_PATH)
 
+    @staticmethod
+    def _x3(name, args):
+        return bool(args) and name in DTYPE_FIRST and isinstance(args[0], int) and not isinstance(args[0], bool) and (args[0] & 0xff) == HYB_F32X3
+
     def call(self, name, *args):
-        if args and args[0] == HYB_F32X3 and name in DTYPE_FIRST and not isinstance(args[0], bool):
-            return self.x3.call(name, HYB_F32, *args[1:])
+        if self._x3(name, args):
+            return self.x3.call(name, HYB_F32 | (args[0] & ~0xff), *args[1:])
         if name in BOTH_BUILDS:            # process-global state that each build keeps for itself (the measurement hooks)
             self.x3.call(name, *args)
         return super().call(name, *args)
 
     def query(self, name, *args):
-        if args and args[0] == HYB_F32X3 and name in DTYPE_FIRST and not isinstance(args[0], bool):
-            return self.x3.query(name, HYB_F32, *args[1:])
+        if self._x3(name, args):
+            return self.x3.query(name, HYB_F32 | (args[0] & ~0xff), *args[1:])
         return super().query(name, *args)
 
 

@@ -374,8 +374,8 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __re
 
 // ---- global average pool ------------------------------------------------------------------
 // one block per (frame, 32-octet slab): 32 octets x 8 pixel groups, LDS combine
-template <typename T>
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ feat, int HW, int Cp, int octBlocks) {
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, TO* __restrict__ feat, int HW, int Cp, int octBlocks) {
     __shared__ float red[8][32][9];
     const int OCT = Cp >> 3;
     const int n = blockIdx.x / octBlocks, ob = blockIdx.x % octBlocks;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T
     for (int j = 0; j < 8; ++j) red[grp][ocl][j] = acc[j];
     __syncthreads();
     if (grp == 0 && oc < OCT) {
-        Vec8<T> o;
+        Vec8<TO> o;
         const float inv = 1.0f / (float)HW;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -417,15 +417,16 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, T
         o.store(feat + (long long)n * Cp + oc * 8);
     }
 }
-template <typename T>
-__global__ void gap_bwd_kernel(const T* __restrict__ dfeat, T* __restrict__ dx, int HW, int Cp, long long total) {
+template <typename T, typename TO = T>
+__global__ void gap_bwd_kernel(const T* __restrict__ dfeat, TO* __restrict__ dx, int HW, int Cp, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int OCT = Cp >> 3;
     const int oc = (int)(i % OCT);
     const long long np = i / OCT;       // n*HW + p
     const long long n = np / HW;
-    Vec8<T> v, o;
+    Vec8<T> v;
+    Vec8<TO> o;
     v.load(dfeat + n * Cp + oc * 8);
     const float inv = 1.0f / (float)HW;
 #pragma unroll
@@ -493,7 +494,7 @@ extern "C" int hyb_profile_clear(void) {
     return 0;
 }
 
-extern "C" int hyb_abi_version(void) { return 8; }
+extern "C" int hyb_abi_version(void) { return 9; }
 extern "C" int hyb_dtype_size(int dtype) { return dtype == HYB_F32 ? 4 : dtype == HYB_BF16 ? 2 : HYB_E_ARG; }
 extern "C" int hyb_pad_channels(int c) { return (c + 31) / 32 * 32; }
 
@@ -592,6 +593,22 @@ extern "C" int hyb_gap_bwd(int dtype, const void* dfeat, void* dx, int N, int HW
     HYB_DISPATCH_T(dtype,
         hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const float*)dfeat, (float*)dx, HW, Cp, total),
         hipLaunchKernelGGL(gap_bwd_kernel<bf16>, dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, (const bf16*)dfeat, (bf16*)dx, HW, Cp, total));
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Internal (hyb_temporal_* with HYB_H_BF16): bf16 pooled map -> fp32 frame features, fp32 feature gradient -> bf16 map gradient
+int hyb_gap_fwd_h16(const void* x, float* feat, int N, int HW, int Cp, hipStream_t st) {
+    if (!x || !feat || N <= 0 || HW <= 0 || Cp % 32 != 0 || Cp <= 0) return HYB_E_ARG;
+    const int octBlocks = hyb_cdiv(Cp / 8, 32);
+    hipLaunchKernelGGL((gap_fwd_kernel<bf16, float>), dim3(N * octBlocks), dim3(256), 0, st, (const bf16*)x, feat, HW, Cp, octBlocks);
+    HYB_LAUNCH_CHECK();
+    return 0;
+}
+int hyb_gap_bwd_h16(const float* dfeat, void* dx, int N, int HW, int Cp, hipStream_t st) {
+    if (!dfeat || !dx || N <= 0 || HW <= 0 || Cp % 32 != 0 || Cp <= 0) return HYB_E_ARG;
+    const long long total = (long long)N * HW * (Cp / 8);
+    hipLaunchKernelGGL((gap_bwd_kernel<float, bf16>), dim3(hyb_cdiv(total, 256)), dim3(256), 0, st, dfeat, (bf16*)dx, HW, Cp, total);
     HYB_LAUNCH_CHECK();
     return 0;
 }

@@ -205,6 +205,9 @@ static int tail_enabled() {
     return env;
 }
 
+int hyb_gap_fwd_h16(const void* x, float* feat, int N, int HW, int Cp, hipStream_t st);      // bn_pool.hip
+int hyb_gap_bwd_h16(const float* dfeat, void* dx, int N, int HW, int Cp, hipStream_t st);
+
 static int temporal_fwd_impl(int dtype, const void* h, const float* token_w, const float* token_b, const float* const* enc_params,
                              const float* head_w, const float* head_b, const float* mask, void* feat, void* tok, void* enc_saved,
                              void* enc_out, float* logits, int B, int S, int HW, int C, int Cp, int D, int Hid, int L, int H, int classes,
@@ -212,7 +215,11 @@ static int temporal_fwd_impl(int dtype, const void* h, const float* token_w, con
                              float* loss, float* ce_scratch, void* stream) {
     HYB_CHECK_ARG(h && token_w && enc_params && head_w && feat && tok && enc_saved && enc_out && logits && B > 0 && S > 0 && HW > 0);
     const int N = B * S;
-    HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
+    const bool h16 = (dtype & HYB_H_BF16) != 0;                 // the pooled map is bf16, everything from the frame features on is fp32
+    dtype &= 0xff;
+    HYB_CHECK_ARG(!h16 || dtype == HYB_F32);
+    if (h16) HYB_TRY(hyb_gap_fwd_h16(h, (float*)feat, N, HW, Cp, (hipStream_t)stream));
+    else HYB_TRY(hyb_gap_fwd(dtype, h, feat, N, HW, Cp, stream));
     // the tokens are written straight into the encoder's saved input slot (`tok` stays an unused scratch argument of the ABI)
     void* tok_dst = (char*)enc_saved + hyb_encoder_xin_offset(dtype, B, S, D, Hid, H);
     (void)tok;
@@ -253,6 +260,9 @@ static int temporal_bwd_impl(int dtype, const float* dlogits, const float* logit
                              unsigned long long seed, const unsigned long long* seed_inc, void* workspace, size_t workspace_bytes, void* stream) {
     HYB_CHECK_ARG((dlogits || (logits && target && dloss)) && token_w && enc_params && head_w && feat && enc_saved && enc_out && dtoken_w && enc_grads &&
                   dhead_w && dh && workspace);
+    const bool h16 = (dtype & HYB_H_BF16) != 0;                 // dh is written as bf16
+    dtype &= 0xff;
+    HYB_CHECK_ARG(!h16 || dtype == HYB_F32);
     if (workspace_bytes < hyb_temporal_bwd_workspace(dtype, B, S, HW, Cp, D, Hid, L, H)) return HYB_E_WORKSPACE;
     const size_t es = dtype == HYB_F32 ? 4 : 2;
     const int N = B * S;
@@ -288,7 +298,8 @@ static int temporal_bwd_impl(int dtype, const float* dlogits, const float* logit
     if (Cp > C) { hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)N * Cp * es, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     HYB_TRY(hyb_linear_bwd(dtype, feat, Cp, token_w, nullptr, dtok, dfeat, 0, ride ? nullptr : dtoken_w, ride ? nullptr : dtoken_b, N, D, C, 0, nullptr, 0,
                            stream));
-    HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));
+    if (h16) HYB_TRY(hyb_gap_bwd_h16((const float*)dfeat, dh, N, HW, Cp, (hipStream_t)stream));
+    else HYB_TRY(hyb_gap_bwd(dtype, dfeat, dh, N, HW, Cp, stream));
     return 0;
 }
 

@@ -905,7 +905,8 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
         else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, none);
         if (hook) hipEventRecord(hook->ev1, st);
-    } else if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
+    } else if (dtype == HYB_F32 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 8>), grid, dim3(512), 0, st, a);      // (the temporal part of 'mixed' / 'bf16x3' / 'fp32')
+    else if (dtype == HYB_F32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && out_f32) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, float, 4>), grid, dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && w8) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8>), grid, dim3(512), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 4>), grid, dim3(256), 0, st, a);

@@ -189,8 +189,15 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         self._dt, self._dt_t = ops.dtype_code(cb), ops.dtype_code(ct)
         return self
 
+    def _temporal_dt(self):
+        """dtype code of the fused temporal operators: bf16 conv stages in front of an fp32-storage temporal part hand their bf16 map over
+        as it is (HYB_H_BF16: the global-average-pool kernels convert, no cast launches)."""
+        if ops.torch_dtype(self._dt) == torch.bfloat16 and ops.torch_dtype(self._dt_t) == torch.float32:
+            return self._dt_t | ops.HYB_H_BF16
+        return self._dt_t
+
     def _to_temporal(self, h):
-        """The last pooled map in the temporal part's storage type (a cast launch each way when the two halves differ: 'mixed')."""
+        """The last pooled map in the temporal part's storage type (unfused path / other pairs: a cast launch each way)."""
         tb, tt = ops.torch_dtype(self._dt), ops.torch_dtype(self._dt_t)
         if tb == tt:
             return h
@@ -235,11 +242,12 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
     def forward_temporal(self, h, B, mask=None):
         """Last pooled map -> frame tokens -> temporal encoder -> head: logits [B, num_classes]."""
         enc = self.encoder
-        h = self._to_temporal(h)
         if self._fused():
-            return ops.temporal(h, self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias, mask, B,
-                                self._dt_t, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
+            tdt = self._temporal_dt()
+            return ops.temporal(h if tdt & ops.HYB_H_BF16 else self._to_temporal(h), self.token_proj.weight, self.token_proj.bias, enc._flat_params(),
+                                self.head.weight, self.head.bias, mask, B, tdt, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
                                 ops.next_seed())
+        h = self._to_temporal(h)
         tok = ops.token(h, self.token_proj.weight, self.token_proj.bias, self._dt_t).reshape(B, h.shape[0] // B, -1)
         return ops.head(enc.forward_compute(tok, mask), self.head.weight, self.head.bias, self._dt_t)
 
@@ -250,8 +258,9 @@ class TransformerCNNHybrid(nn.Module, _ComputeDtypeMixin):
         if not self._fused():
             logits = self.forward_temporal(h, B, mask)
             return ops.cross_entropy(logits, target), logits
-        return ops.temporal_ce(self._to_temporal(h), self.token_proj.weight, self.token_proj.bias, enc._flat_params(), self.head.weight, self.head.bias,
-                               mask, target, B, self._dt_t, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
+        tdt = self._temporal_dt()
+        return ops.temporal_ce(h if tdt & ops.HYB_H_BF16 else self._to_temporal(h), self.token_proj.weight, self.token_proj.bias, enc._flat_params(),
+                               self.head.weight, self.head.bias, mask, target, B, tdt, enc.hidden_dim, enc.num_layers, enc.num_heads, enc.attention_layers[0]._attn_p(), float(enc.dropout),
                                ops.next_seed())
 
     def backbone_parameters(self):

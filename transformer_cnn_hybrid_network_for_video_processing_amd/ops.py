@@ -29,7 +29,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from ._lib import HYB_BF16, HYB_F32, HYB_F32X3, lib, ptr_array
+from ._lib import HYB_BF16, HYB_F32, HYB_F32X3, HYB_H_BF16, lib, ptr_array
 
 _TORCH_DTYPE = {HYB_F32: torch.float32, HYB_BF16: torch.bfloat16, HYB_F32X3: torch.float32}
 _LIB = torch.library.Library("hybrid", "DEF")
@@ -790,22 +790,32 @@ def backbone(x, stages, training, dt):
     return res[0]
 
 
+def _check_h_dtype(h, dt):
+    """dt | HYB_H_BF16 (fp32 / bf16x3 temporal part behind bf16 conv stages): the pooled map is bf16, the global-average-pool kernels convert."""
+    want = torch.bfloat16 if dt & HYB_H_BF16 else _TORCH_DTYPE[dt & 0xff]
+    if dt & HYB_H_BF16 and _TORCH_DTYPE[dt & 0xff] != torch.float32:
+        raise ValueError("HYB_H_BF16 goes with an fp32-storage temporal part ('fp32' / 'bf16x3')")
+    if h.dtype != want:
+        raise TypeError(f"the pooled map must be {want} for this compute dtype, got {h.dtype}")
+
+
 def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, head_b: Tensor, mask: Optional[Tensor],
                 B: int, dt: int, hid: int, L: int, H: int, attn_p: float, layer_p: float, seed: int,
                 seed_inc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """h [B*S, Hh, Ww, Cp] T (last pooled map) -> (logits [B, classes] fp32, feat, enc_saved, enc_out); the last three are saved for backward."""
     _require_cuda(h, token_w, head_w, *enc_params)
+    _check_h_dtype(h, dt)
     h = h.contiguous()
     N, Hh, Ww, Cp = h.shape
     S = N // B
     D, C = token_w.shape
     classes = head_w.shape[0]
     _check_attention_limits(S, D, H)
-    dev, tdt = h.device, _TORCH_DTYPE[dt]
+    dev, tdt = h.device, _TORCH_DTYPE[dt & 0xff]
     feat = torch.empty(N, Cp, dtype=tdt, device=dev)
     tok = torch.empty(B, S, D, dtype=tdt, device=dev)
     enc_out = torch.empty(B, S, D, dtype=tdt, device=dev)
-    saved = _ws(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), dev)
+    saved = _ws(_query("hyb_encoder_saved_bytes", dt & 0xff, B, S, D, hid, L, H), dev)
     logits = torch.empty(B, classes, dtype=torch.float32, device=dev)
     ps = [p.contiguous() for p in enc_params]
     lib.call("hyb_temporal_fwd", dt, h.data_ptr(), token_w.contiguous().data_ptr(), token_b.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
@@ -818,9 +828,9 @@ def temporal_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequenc
 def temporal_fake(h, token_w, token_b, enc_params, head_w, head_b, mask, B, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     N, Hh, Ww, Cp = h.shape
     S, D = N // B, token_w.shape[0]
-    tdt = _TORCH_DTYPE[dt]
+    tdt = _TORCH_DTYPE[dt & 0xff]
     return (h.new_empty((B, head_w.shape[0]), dtype=torch.float32), h.new_empty((N, Cp), dtype=tdt),
-            h.new_empty((max(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), 256),), dtype=torch.uint8), h.new_empty((B, S, D), dtype=tdt))
+            h.new_empty((max(_query("hyb_encoder_saved_bytes", dt & 0xff, B, S, D, hid, L, H), 256),), dtype=torch.uint8), h.new_empty((B, S, D), dtype=tdt))
 
 
 def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tensor], head_w: Tensor, mask: Optional[Tensor], feat: Tensor,
@@ -832,16 +842,16 @@ def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tenso
     N, Cp = feat.shape
     C = token_w.shape[1]
     classes = head_w.shape[0]
-    dev, tdt = feat.device, _TORCH_DTYPE[dt]
+    dev, tdt = feat.device, _TORCH_DTYPE[dt & 0xff]
     dlogits = dlogits.contiguous().float()
     ps = [p.contiguous() for p in enc_params]
     grads = [torch.empty_like(p) for p in ps]
-    dh = torch.empty(N, Hh, Ww, Cp, dtype=tdt, device=dev)
+    dh = torch.empty(N, Hh, Ww, Cp, dtype=torch.bfloat16 if dt & HYB_H_BF16 else tdt, device=dev)
     dtw = torch.empty_like(token_w, memory_format=torch.contiguous_format)
     dtb = torch.empty(D, dtype=torch.float32, device=dev)
     dhw = torch.empty_like(head_w, memory_format=torch.contiguous_format)
     dhb = torch.empty(classes, dtype=torch.float32, device=dev)
-    ws = _ws(_query("hyb_temporal_bwd_workspace", dt, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
+    ws = _ws(_query("hyb_temporal_bwd_workspace", dt & 0xff, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
     lib.call("hyb_temporal_bwd", dt, dlogits.data_ptr(), token_w.contiguous().data_ptr(), ptr_array([p.data_ptr() for p in ps]),
              head_w.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), saved.data_ptr(), enc_out.data_ptr(), dtw.data_ptr(), dtb.data_ptr(),
              ptr_array([g.data_ptr() for g in grads]), dhw.data_ptr(), dhb.data_ptr(), dh.data_ptr(), B, S, Hh * Ww, C, Cp, D, hid, L, H, classes,
@@ -852,7 +862,7 @@ def temporal_bwd_op(dlogits: Tensor, token_w: Tensor, enc_params: Sequence[Tenso
 def temporal_bwd_fake(dlogits, token_w, enc_params, head_w, mask, feat, saved, enc_out, Hh, Ww, dt, hid, L, H, attn_p, layer_p, seed, seed_inc=None):
     N, Cp = feat.shape
     c = lambda t: torch.empty_like(t, memory_format=torch.contiguous_format)
-    return [feat.new_empty((N, Hh, Ww, Cp)), c(token_w), feat.new_empty((token_w.shape[0],), dtype=torch.float32), c(head_w),
+    return [feat.new_empty((N, Hh, Ww, Cp), dtype=torch.bfloat16 if dt & HYB_H_BF16 else feat.dtype), c(token_w), feat.new_empty((token_w.shape[0],), dtype=torch.float32), c(head_w),
             feat.new_empty((head_w.shape[0],), dtype=torch.float32)] + [c(p) for p in enc_params]
 
 
@@ -878,6 +888,7 @@ def temporal_ce_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequ
                    seed_inc: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """hybrid::temporal + hybrid::cross_entropy in the same launches (hyb_temporal_ce_fwd): -> (loss [], logits, feat, enc_saved, enc_out)."""
     _require_cuda(h, token_w, head_w, target, *enc_params)
+    _check_h_dtype(h, dt)
     h = h.contiguous()
     N, Hh, Ww, Cp = h.shape
     S = N // B
@@ -887,11 +898,11 @@ def temporal_ce_op(h: Tensor, token_w: Tensor, token_b: Tensor, enc_params: Sequ
     if target.dim() != 1 or target.shape[0] != B:
         raise ValueError(f"expected class indices [B={B}], got {tuple(target.shape)}")
     target = target.contiguous().to(torch.int64)
-    dev, tdt = h.device, _TORCH_DTYPE[dt]
+    dev, tdt = h.device, _TORCH_DTYPE[dt & 0xff]
     feat = torch.empty(N, Cp, dtype=tdt, device=dev)
     tok = torch.empty(B, S, D, dtype=tdt, device=dev)
     enc_out = torch.empty(B, S, D, dtype=tdt, device=dev)
-    saved = _ws(_query("hyb_encoder_saved_bytes", dt, B, S, D, hid, L, H), dev)
+    saved = _ws(_query("hyb_encoder_saved_bytes", dt & 0xff, B, S, D, hid, L, H), dev)
     logits = torch.empty(B, classes, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     ps = [p.contiguous() for p in enc_params]
@@ -915,16 +926,16 @@ def temporal_ce_bwd_op(dloss: Tensor, logits: Tensor, target: Tensor, token_w: T
     N, Cp = feat.shape
     C = token_w.shape[1]
     classes = head_w.shape[0]
-    dev, tdt = feat.device, _TORCH_DTYPE[dt]
+    dev, tdt = feat.device, _TORCH_DTYPE[dt & 0xff]
     dl = dloss.contiguous().float().reshape(1)
     ps = [p.contiguous() for p in enc_params]
     grads = [torch.empty_like(p) for p in ps]
-    dh = torch.empty(N, Hh, Ww, Cp, dtype=tdt, device=dev)
+    dh = torch.empty(N, Hh, Ww, Cp, dtype=torch.bfloat16 if dt & HYB_H_BF16 else tdt, device=dev)
     dtw = torch.empty_like(token_w, memory_format=torch.contiguous_format)
     dtb = torch.empty(D, dtype=torch.float32, device=dev)
     dhw = torch.empty_like(head_w, memory_format=torch.contiguous_format)
     dhb = torch.empty(classes, dtype=torch.float32, device=dev)
-    ws = _ws(_query("hyb_temporal_bwd_workspace", dt, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
+    ws = _ws(_query("hyb_temporal_bwd_workspace", dt & 0xff, B, S, Hh * Ww, Cp, D, hid, L, H), dev)
     lib.call("hyb_temporal_ce_bwd", dt, dl.data_ptr(), logits.contiguous().data_ptr(), target.contiguous().data_ptr(), token_w.contiguous().data_ptr(),
              ptr_array([p.data_ptr() for p in ps]), head_w.contiguous().data_ptr(), _opt_ptr(mask), feat.data_ptr(), saved.data_ptr(), enc_out.data_ptr(),
              dtw.data_ptr(), dtb.data_ptr(), ptr_array([g.data_ptr() for g in grads]), dhw.data_ptr(), dhb.data_ptr(), dh.data_ptr(), B, S, Hh * Ww, C, Cp,
