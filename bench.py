@@ -395,6 +395,8 @@ def entry_point_roofline(totals, passes):
 def committed_traffic(kernel, cfgno, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 +
     WRITE_SIZE, separate passes, per configuration and mode) -- (bytes, source) or (None, None)."""
+    if dtype == "mixed":          # the conv stages of `mixed` are the bf16 mode's kernels on the same tensors
+        dtype = "bf16"
     for tname in ("r04_traffic.json",):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
