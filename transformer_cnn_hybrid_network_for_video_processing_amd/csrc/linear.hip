@@ -17,7 +17,7 @@ int hyb_gemm_nt(int dtype, int groups, const void* const* A, const void* const* 
 int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void* const* mask, const void* const* x, float* const* dW,
                         float* const* db, const int* N, const int* K, const int* lddy, const int* ldx, int M, hipStream_t st,
                         int nriders, const HybDwRider* riders);
-int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
+int hyb_gemm_skinny_wf32(int dtype, const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
                          int accumulate, int transposed_b, hipStream_t st);
 
 namespace {
@@ -276,6 +276,98 @@ __global__ __launch_bounds__(256) void gemm_dw_multi_tr_kernel(DwArgs args) {
             for (int i = 0; i < 2; ++i) dwt_frag(a[i], As, k0, wm * 32 + i * 16, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) dwt_frag(b[j], Bs, k0, wn * 32 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
+        }
+    }
+    if (grp.db && bx == 0 && tid < 64 && m0 + tid < grp.N) grp.db[m0 + tid] = csum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int no = n0 + wn * 32 + j * 16 + p;
+            if (no >= grp.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = m0 + wm * 32 + i * 16 + 4 * q + r;
+                if (mo < grp.N) grp.dW[(long long)mo * grp.K + no] = acc[i][j][r];
+            }
+        }
+}
+
+// fp32-storage twin of gemm_dw_multi_tr_kernel ('fp32' / 'bf16x3' modes and the temporal part of 'mixed'): both operand tiles staged as
+// they lie in memory, all of up to 128 rows in one round, 16-byte loads and stores; a fragment's 8 K values are 8 consecutive ROWS of one
+// column, read as eight ds_read_b32 (16 lanes = 16 consecutive columns: conflict-free).  69.6 KB of LDS (dynamic).
+constexpr int DWF_ROWS = 128, DWF_STRIDE = 64 + 4;
+__device__ __forceinline__ void dwf_frag(Frag<float>& f, const float* tile, int m0, int c0, int lane) {
+    const float* a0 = tile + (m0 + 8 * (lane >> 4)) * DWF_STRIDE + c0 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = a0[j * DWF_STRIDE];
+}
+__global__ __launch_bounds__(256) void gemm_dw_multi_trf_kernel(DwArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float dwf_smem[];
+    float* const As = dwf_smem;
+    float* const Bs = dwf_smem + DWF_ROWS * DWF_STRIDE;
+    if ((int)blockIdx.x >= args.tiles) { dw_rider_block(args); return; }
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < DW_MAX_GROUPS; ++i)
+        if (i < args.ngroups && (int)blockIdx.x >= args.g[i].tile_begin) gi = i;
+    const DwGroup grp = args.g[gi];
+    const int local = blockIdx.x - grp.tile_begin;
+    const int bx = local % grp.tiles_x, by = local / grp.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = by * 64, n0 = bx * 64;                  // m0: rows of dW (columns of dy), n0: columns of dW (columns of x)
+    const int p = lane & 15, q = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const float* dy = (const float*)grp.dy;
+    const float* mk = (const float*)grp.mask;
+    const float* x = (const float*)grp.x;
+    const int seg = tid & 15, row_t = tid >> 4;            // thread: 4 columns seg*4.., rows row_t + 16 u
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < args.M; r0 += DWF_ROWS) {
+        if (r0 > 0) __syncthreads();
+        f32x4 va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + row_t + 16 * u;
+            const bool rok = r < args.M;
+            va[u] = z4; vb[u] = z4;
+            if (rok && m0 + seg * 4 < grp.N) {
+                va[u] = *reinterpret_cast<const f32x4*>(dy + (long long)r * grp.lddy + m0 + seg * 4);
+                if (mk) {
+                    const f32x4 vm = *reinterpret_cast<const f32x4*>(mk + (long long)r * grp.lddy + m0 + seg * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!(vm[j] > 0.f)) va[u][j] = 0.f;
+                }
+            }
+            if (rok && n0 + seg * 4 < grp.K) vb[u] = *reinterpret_cast<const f32x4*>(x + (long long)r * grp.ldx + n0 + seg * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            *reinterpret_cast<f32x4*>(As + (row_t + 16 * u) * DWF_STRIDE + seg * 4) = va[u];
+            *reinterpret_cast<f32x4*>(Bs + (row_t + 16 * u) * DWF_STRIDE + seg * 4) = vb[u];
+        }
+        __syncthreads();
+        const int rows = args.M - r0 < DWF_ROWS ? args.M - r0 : DWF_ROWS;
+        if (grp.db && bx == 0 && tid < 64) {                // bias gradient: column sums of the (masked) dy tile, rows in ascending order
+            for (int r = 0; r < rows; ++r) csum += As[r * DWF_STRIDE + tid];
+        }
+        for (int k0 = 0; k0 < rows; k0 += 32) {             // rows beyond M are zero: a ragged last step contributes nothing
+            Frag<float> a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dwf_frag(a[i], As, k0, wm * 32 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dwf_frag(b[j], Bs, k0, wn * 32 + j * 16, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -805,8 +897,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 
 template <typename T>
 int linear_fwd_t(const void* x, int ldx, const float* W, const float* b, void* y, int M, int N, int K, int relu, hipStream_t st) {
-    if (sizeof(T) == 2) {                                   // few-tile products: eight waves split K, fragments straight from the master weights
-        const int rc = hyb_gemm_skinny_wf32(x, W, y, b, M, N, K, ldx, K, N, relu, 0, 0, st);
+    {                                                       // few-tile products: eight waves split K, fragments straight from the master weights
+        const int rc = hyb_gemm_skinny_wf32(sizeof(T) == 2 ? HYB_BF16 : HYB_F32, x, W, y, b, M, N, K, ldx, K, N, relu, 0, 0, st);
         if (rc != -100) return rc;
     }
     GemmArgs a{};
@@ -835,7 +927,7 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         int rc = hyb_gemm_nt(sizeof(T) == 4 ? HYB_F32 : HYB_BF16, 1, A_, B_, C_, nullptr, 0, M, K, N, N, N, ldx, 0, accumulate_dx, st);
         if (rc) return rc;
     } else if (dx) { // dx[m][k] = sum_n dym[m][n] * W[n][k]
-        int rc = sizeof(T) == 2 ? hyb_gemm_skinny_wf32(dym, W, dx, nullptr, M, K, N, N, K, ldx, 0, accumulate_dx, 1, st) : -100;
+        int rc = hyb_gemm_skinny_wf32(sizeof(T) == 2 ? HYB_BF16 : HYB_F32, dym, W, dx, nullptr, M, K, N, N, K, ldx, 0, accumulate_dx, 1, st);
         if (rc != -100 && rc != 0) return rc;
         if (rc == -100) {            // not a few-tile shape: the LDS-staged kernel
         GemmArgs a{};
@@ -845,12 +937,12 @@ int linear_bwd_t(const void* x, int ldx, const float* W, const void* Wt, const v
         if (rc) return rc;
         }
     }
-    if (dW && sizeof(T) == 2 && N % 8 == 0 && K % 8 == 0) {
-        // bf16: the multi-matrix weight-gradient kernel with one matrix -- the model-level path computes the same gradient as one group of
+    if (dW && N % 8 == 0 && K % 8 == 0) {
+        // the multi-matrix weight-gradient kernel with one matrix -- the model-level path computes the same gradient as one group of
         // its encoder launch, and the two must agree bit for bit
         const void* dy_[1] = {dym}; const void* x_[1] = {x}; float* dW_[1] = {dW}; float* db_[1] = {db};
         const int N_[1] = {N}, K_[1] = {K}, lddy_[1] = {N}, ldx_[1] = {ldx};
-        int rc = hyb_linear_dw_multi(HYB_BF16, 1, dy_, nullptr, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 0, nullptr);
+        int rc = hyb_linear_dw_multi(sizeof(T) == 2 ? HYB_BF16 : HYB_F32, 1, dy_, nullptr, x_, dW_, db_, N_, K_, lddy_, ldx_, M, st, 0, nullptr);
         if (rc) return rc;
     } else if (dW) {        // dW[n][k] = sum_m dym[m][n] * x[m][k]; the bias gradient (column sums of dym) rides in the same launch
         GemmArgs a{};
@@ -940,7 +1032,7 @@ int hyb_gemm_nt_ln(int dtype, int groups, const void* x, const void* skip, const
 
 // Internal: skinny product on the fp32 master weights (BMODE 1 / 2 of gemm_nt_splitk_kernel), bf16 activations; returns -100 when the
 // shape is not a few-tile one (the caller then takes the LDS-staged kernel)
-int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
+int hyb_gemm_skinny_wf32(int dtype, const void* A, const float* Bf, void* C, const float* bias, int Mo, int No, int R, int lda, int ldb, int ldc, int relu,
                          int accumulate, int transposed_b, hipStream_t st) {
     static const int env = getenv("HYB_GEMM_WF32") ? atoi(getenv("HYB_GEMM_WF32")) : 1;
     const dim3 grid(hyb_cdiv(No, 32), hyb_cdiv(Mo, 32), 1);
@@ -949,7 +1041,10 @@ int hyb_gemm_skinny_wf32(const void* A, const float* Bf, void* C, const float* b
     GemmArgs a{};
     a.g[0] = GemmGroup{A, Bf, C, bias, nullptr, nullptr};
     a.Mo = Mo; a.No = No; a.R = R; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
-    if (transposed_b) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8, 2>), grid, dim3(512), 0, st, a);
+    if (dtype == HYB_F32) {        // fp32 storage ('fp32' / 'bf16x3' / the temporal part of 'mixed'): the weights are read as they are
+        if (transposed_b) hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 8, 2>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_splitk_kernel<float, float, 8, 0>), grid, dim3(512), 0, st, a);
+    } else if (transposed_b) hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8, 2>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((gemm_nt_splitk_kernel<bf16, bf16, 8, 1>), grid, dim3(512), 0, st, a);
     HYB_LAUNCH_CHECK();
     return 0;
@@ -1027,7 +1122,16 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
     for (int i = 0; i < groups; ++i)
         aligned = aligned && lddy[i] % 8 == 0 && ldx[i] % 8 == 0 && ((uintptr_t)dy[i] % 16 == 0) && ((uintptr_t)x[i] % 16 == 0) &&
                   (!mask || !mask[i] || (uintptr_t)mask[i] % 16 == 0);
-    if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    bool aligned4 = true;                                  // fp32 rows: 16-byte = 4-element alignment
+    for (int i = 0; i < groups; ++i)
+        aligned4 = aligned4 && lddy[i] % 4 == 0 && ldx[i] % 4 == 0 && N[i] % 4 == 0 && K[i] % 4 == 0 && ((uintptr_t)dy[i] % 16 == 0) &&
+                   ((uintptr_t)x[i] % 16 == 0) && (!mask || !mask[i] || (uintptr_t)mask[i] % 16 == 0);
+    if (dtype == HYB_F32 && tr_env && aligned4) {
+        constexpr int lds = 2 * DWF_ROWS * DWF_STRIDE * (int)sizeof(float);
+        static HybAttrOnce once;
+        if (int e = hyb_set_lds_attr(once, (const void*)gemm_dw_multi_trf_kernel, lds)) return e;
+        hipLaunchKernelGGL(gemm_dw_multi_trf_kernel, dim3(blocks), dim3(256), lds, st, a);
+    } else if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && tr_env && aligned) hipLaunchKernelGGL(gemm_dw_multi_tr_kernel, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, st, a);
     else return HYB_E_ARG;
