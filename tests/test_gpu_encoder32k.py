@@ -52,6 +52,15 @@ CONV_CASES = [  # k, stride, pad, dil, ci, co, n, h, w, bias
     (1, 2, 0, 1, 32, 64, 2, 80, 80, False),     # 1x1 stride 2 gathered in place
     (3, 2, 1, 1, 16, 16, 2, 90, 91, False),     # 3x3 stride 2: implicit forward, col2im dgrad
     (3, 1, 1, 1, 64, 4, 1, 64, 64, True),       # Co = 4 -> Co8 = 8 (padded gradient channels)
+    # the LDS-tiled kernels (gemm_nt_lds_kernel: >= 64 columns; wgrad_lds_kernel: >= 64 x 64 outputs, >= 4096 pixels): ragged row blocks,
+    # ragged column tiles, K tails, strides and dilations through the out-of-range-lane gather
+    (3, 1, 1, 1, 64, 72, 3, 40, 40, True),      # 4800 rows (not a multiple of 128), 72 columns in a 128-wide tile, K = 576 (192-wide k tiles)
+    (1, 1, 0, 1, 32, 136, 2, 48, 48, False),    # 1x1: the plain GEMM, a ragged second column tile; K = 32: weight gradient on the direct kernel
+    (1, 1, 0, 1, 256, 256, 5, 29, 29, True),    # 4205 rows, 2 x 2 tiles of 128
+    (3, 2, 1, 1, 128, 64, 2, 96, 96, False),    # stride 2: implicit forward and implicit weight gradient, col2im input gradient
+    (3, 1, 2, 2, 16, 64, 2, 48, 48, True),      # dilation 2 over 16 channels: a 32-deep step spans two taps
+    (3, 1, 1, 1, 128, 128, 1, 72, 72, False),   # 128 x 128 tiles in all three products, K = 1152
+    (3, 1, 1, 1, 64, 192, 2, 48, 47, True),     # odd width, 192 columns (a full and a half tile)
 ]
 
 

@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void convert_weights_kernel(ConvertArgs a) {
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
         float v = 0.f;
-        if (n < N && k < K) { v = W[(long long)n * K + k]; Wc[(long long)n * K + k] = from_f32<T>(v); }
+        if (n < N && k < K) { v = W[(long long)n * K + k]; if (Wc) Wc[(long long)n * K + k] = from_f32<T>(v); }
         tile[r][tx] = v;
     }
     __syncthreads();
@@ -842,7 +842,8 @@ __global__ __launch_bounds__(256) void convert_weights_vec_kernel(ConvertArgs a)
             T o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = from_f32<T>(v[j]);
-            if (sizeof(T) == 2) *reinterpret_cast<unsigned long long*>(Wc + (long long)n * K + k) = *reinterpret_cast<const unsigned long long*>(o);
+            if (!Wc) {}                                         // (fp32 storage: the forward reads the master weights in place)
+            else if (sizeof(T) == 2) *reinterpret_cast<unsigned long long*>(Wc + (long long)n * K + k) = *reinterpret_cast<const unsigned long long*>(o);
             else *reinterpret_cast<f32x4*>(Wc + (long long)n * K + k) = *reinterpret_cast<const f32x4*>(o);
         }
 #pragma unroll

@@ -86,7 +86,8 @@ inline EncLayout enc_layout(int dtype, int B, int S, int D, int Hid, int H) {
     L.long_ws_bytes = S > 64 ? hyb_attention_long_workspace(dtype, B, S, D, H) : 0;
     L.long_ws = take(L.long_ws_bytes);
     const size_t wsz[6] = {(size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)D * D, (size_t)Hid * D, (size_t)D * Hid};
-    for (int i = 0; i < 6; ++i) L.wc[i] = take(wsz[i] * es);
+    // (fp32 storage: the forward reads the master weights in place, no plain copies -- only the transposed ones below)
+    for (int i = 0; i < 6; ++i) L.wc[i] = take(dtype == HYB_F32 ? 0 : wsz[i] * es);
     L.wt[0] = take(3 * wsz[0] * es);
     L.wt[1] = L.wt[0] + (size_t)D * es;
     L.wt[2] = L.wt[0] + 2 * (size_t)D * es;
@@ -267,6 +268,9 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
     char* sv = (char*)saved;
     if ((const void*)x != (const void*)(sv + lay.x_in))       // (hyb_temporal_fwd writes the tokens there directly)
         HYB_HIP_TRY(hipMemcpyAsync(sv + lay.x_in, x, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+    const bool wc_master = dtype == HYB_F32;                 // fp32 storage: the forward reads the master weights in place (16-byte fragment loads)
+    for (int i = 0; i < L && wc_master; ++i)
+        for (int j = 0; j < 6; ++j) HYB_CHECK_ARG((uintptr_t)params[(size_t)i * 14 + 2 * j] % 16 == 0);
     if (L <= 3) {   // the weight copies of every layer in ONE launch (they depend on the master weights only)
         const float* Wsrc[18]; void* Wc[18]; void* Wt[18]; int Ns[18], Ks[18], ldt[18];
         for (int i = 0; i < L; ++i) {
@@ -274,7 +278,7 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
             const float* const* P = params + (size_t)i * 14;
             const int n6[6] = {D, D, D, D, Hid, D}, k6[6] = {D, D, D, D, D, Hid}, l6[6] = {3 * D, 3 * D, 3 * D, D, Hid, D};
             for (int j = 0; j < 6; ++j) {
-                Wsrc[i * 6 + j] = P[2 * j]; Wc[i * 6 + j] = base + lay.wc[j]; Wt[i * 6 + j] = base + lay.wt[j];
+                Wsrc[i * 6 + j] = P[2 * j]; Wc[i * 6 + j] = wc_master ? nullptr : base + lay.wc[j]; Wt[i * 6 + j] = base + lay.wt[j];
                 Ns[i * 6 + j] = n6[j]; Ks[i * 6 + j] = k6[j]; ldt[i * 6 + j] = l6[j];
             }
         }
@@ -289,12 +293,14 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
         if (L > 3) {   // fp32 master weights -> T copies (plain for forward, transposed for dX); deep stacks: one launch per layer
             const float* Wsrc[6] = {P[0], P[2], P[4], P[6], P[8], P[10]};
             void* Wc[6]; void* Wt[6];
-            for (int j = 0; j < 6; ++j) { Wc[j] = base + lay.wc[j]; Wt[j] = base + lay.wt[j]; }
+            for (int j = 0; j < 6; ++j) { Wc[j] = wc_master ? nullptr : base + lay.wc[j]; Wt[j] = base + lay.wt[j]; }
             const int Ns[6] = {D, D, D, D, Hid, D}, Ks[6] = {D, D, D, D, D, Hid};
             const int ldt[6] = {3 * D, 3 * D, 3 * D, D, Hid, D};
             HYB_TRY(hyb_convert_weights(dtype, 6, Wsrc, Wc, Wt, Ns, Ks, ldt, st));
         }
-        const void* Wq3[3] = {base + lay.wc[0], base + lay.wc[1], base + lay.wc[2]};
+        // the forward's weight operands: the T copies, or -- fp32 storage -- the master weights themselves (no copy is written)
+        auto WC = [&](int j) -> const void* { return wc_master ? (const void*)P[2 * j] : (const void*)(base + lay.wc[j]); };
+        const void* Wq3[3] = {WC(0), WC(1), WC(2)};
         const float* bs[3] = {P[1], P[3], P[5]};
         void* ys[3] = {base + lay.qkv, base + lay.qkv + (size_t)D * es, base + lay.qkv + 2 * (size_t)D * es};
         // Q | K | V projections (src L69-70).  From the second layer on their input is the previous layer's second LayerNorm (src L120-123), which
@@ -322,11 +328,11 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
         else
         HYB_TRY(hyb_attention_fwd_packed(dtype, base + lay.qkv, mask, base + lay.attn, (float*)(base + lay.probs), B, S, D, H, attn_p,
                                          attn_seed(seed, i), seed_inc, st));                                          // src L73-84
-        { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {base + lay.wc[3]}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
+        { const void* A_[1] = {base + lay.attn}; const void* B_[1] = {WC(3)}; void* C_[1] = {base + lay.o}; const float* b_[1] = {P[7]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, D, D, D, D, 0, 0, st)); }                            // src L87
         // first LayerNorm (src L116-117) + the feed-forward's first Linear with ReLU (src L119): one launch when the shape allows
         {
-            const void* B_[1] = {base + lay.wc[4]}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
+            const void* B_[1] = {WC(4)}; void* C_[1] = {base + lay.hmid}; const float* b_[1] = {P[9]};
             const int rc = hyb_gemm_nt_ln(dtype, 1, base + lay.o, x_in, P[12], P[13], base + lay.x1, (float*)(base + lay.st1), 1e-5f, 1.0f, 0.f, 0ull,
                                           nullptr, B_, C_, b_, M, Hid, D, D, Hid, 1, st);
             if (rc == -100) {
@@ -336,7 +342,7 @@ int hyb_encoder_fwd_impl(int dtype, const void* x, const float* mask, const floa
                 HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, Hid, D, D, D, Hid, 1, 0, st));
             } else if (rc != 0) return rc;
         }
-        { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {base + lay.wc[5]}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
+        { const void* A_[1] = {base + lay.hmid}; const void* B_[1] = {WC(5)}; void* C_[1] = {base + lay.f}; const float* b_[1] = {P[11]};
           HYB_TRY(hyb_gemm_nt(dtype, 1, A_, B_, C_, b_, 0, M, D, Hid, Hid, Hid, D, 0, 0, st)); }                      // src L119 (Linear)
         if (tail && i == L - 1) {
             *tail = HybEncTail{base + lay.f, base + lay.x1, (float*)(base + lay.st2), P[12], P[13], 1e-5f, (float)sqrt(0.5), layer_p, drop_seed(seed, i)};
