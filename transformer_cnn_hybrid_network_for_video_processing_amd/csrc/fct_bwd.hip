@@ -608,8 +608,10 @@ int hyb_sliced_wgrad_cs(const float* dy, int lddy, const float* x, int ldx, floa
     int ntl, ktl, rows, S;
     direct_geometry(P, Nn, K, ntl, ktl, rows, S);
     float* cpart = colsum ? (float*)cws : nullptr;
-    WlPlan pl;
-    if (wl_plan(pl, P, Nn, K, lddy, ldx, dy, x, geo)) {
+    WlPlan pl, cap;
+    // (slices shortened for 32-bit addressing may need more slabs than hyb_sliced_wgrad_workspace promised: then the direct kernel runs)
+    const int s_cap = wl_plan(cap, P, Nn, K, 4, 4, nullptr, nullptr, nullptr) ? (cap.S > S ? cap.S : S) : S;
+    if (wl_plan(pl, P, Nn, K, lddy, ldx, dy, x, geo) && pl.S <= (s_cap > hyb_cdiv(P, SLICE_ROWS) ? s_cap : hyb_cdiv(P, SLICE_ROWS))) {
         S = pl.S;
         wl_launch(pl, dy, lddy, x, ldx, (float*)ws, cpart, P, Nn, K, st, geo);
     } else if (legacy && !geo) {

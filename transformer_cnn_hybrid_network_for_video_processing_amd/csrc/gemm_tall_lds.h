@@ -187,7 +187,8 @@ bool gt_lds_ok(const GemmArgs& a, bool implicit) {
     static const int env = getenv("HYB_GEMM_LDS") ? atoi(getenv("HYB_GEMM_LDS")) : 1;
     if (!env || a.No < 64 || a.R % 4 != 0 || a.ldb % 4 != 0) return false;
     if (((uintptr_t)a.g[0].A | (uintptr_t)a.g[0].B) & 15) return false;
-    if (!implicit && a.lda % 4 != 0) return false;
+    if (!implicit && (a.lda % 4 != 0 || (long long)a.lda * 128 * 4 >= 0x7fffffffll)) return false;      // (32-bit byte offsets inside a 128-row block)
+    if ((long long)a.ldb * 128 * 4 >= 0x7fffffffll) return false;
     return true;
 }
 

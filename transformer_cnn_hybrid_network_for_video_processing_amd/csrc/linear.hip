@@ -1073,7 +1073,8 @@ int hyb_conv_implicit_gemm(const float* x, const float* wp, const float* bias, f
     if (blocks > 0x7fffffff) return HYB_E_ARG;
     HybProfileHook* hook = hyb_find_hook(4, Co, Kp);          // measurement hook (hyb_profile_set): kernel 4 = the tall GEMM, keyed by (columns, K)
     if (hook) hipEventRecord(hook->ev0, st);
-    if (Ci >= 4 && gt_lds_ok(a, true)) { const int rc = gt_launch<true>(a, cg, st); if (rc) return rc; }
+    // (the LDS kernel addresses its 128 rows relative to their first image with 32-bit byte offsets: two images must fit 2^31 bytes)
+    if (Ci >= 4 && (long long)H * W * Ci * 8 < 0x7fffffffll && gt_lds_ok(a, true)) { const int rc = gt_launch<true>(a, cg, st); if (rc) return rc; }
     else if (nt == 4) hipLaunchKernelGGL((gemm_nt_tall_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else if (nt == 2) hipLaunchKernelGGL((gemm_nt_tall_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);
     else hipLaunchKernelGGL((gemm_nt_tall_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, tiles_n, row_blocks, cg);

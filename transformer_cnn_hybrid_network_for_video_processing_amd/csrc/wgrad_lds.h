@@ -183,6 +183,15 @@ inline bool wl_plan(WlPlan& pl, long long P, int Nn, int K, int lddy, int ldx, c
     long long r = (P + S - 1) / S;
     r = (r + WL_PB - 1) / WL_PB * WL_PB;
     if (r < 256) r = 256;
+    // the kernel addresses a slice with 32-bit byte offsets from its first row (dy, plain x) / its first image (IMPL): shorten the slices until
+    // every operand's slice fits 2^31 bytes (more slabs), give up below 256 rows
+    auto fits = [&](long long rows) {
+        if (rows * lddy * 4 >= 0x7fffffffll) return false;
+        if (geo) return (rows / ((long long)geo->Ho * geo->Wo) + 2) * geo->H * geo->W * geo->Ci * 4 < 0x7fffffffll;
+        return rows * ldx * 4 < 0x7fffffffll;
+    };
+    while (!fits(r) && r > 256) r = ((r / 2) + WL_PB - 1) / WL_PB * WL_PB;
+    if (!fits(r) || (P + r - 1) / r > 2048) return false;       // (the bias-gradient partials are sized for <= 2064 slices)
     pl.rows = (int)r;
     pl.S = (int)((P + r - 1) / r);
     return true;
