@@ -407,6 +407,18 @@ def committed_traffic(kernel, cfgno, dtype):
     return None, None
 
 
+def committed_traffic_f(leg, kernel):
+    """HBM bytes of the heaviest launch of `kernel` in one training pass of the fct / enc32k benches, from the committed counter passes
+    (profiles/r04_traffic_f.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; scripts/collect_pmc_f_r04.sh) -- (bytes, source)."""
+    tpath = os.path.join(ROOT, "profiles", "r04_traffic_f.json")
+    if os.path.exists(tpath):
+        for k, v in json.load(open(tpath)).get(leg, {}).items():
+            if kernel in k:
+                return v["hbm_bytes_per_launch_max"], ("profiles/r04_traffic_f.json [%s][%s]: the launch of this kernel name with the most traffic in the pass "
+                                                       "(the hooked launch is the heaviest of its name); not re-measured in this run" % (leg, k))
+    return None, None
+
+
 def hooked_kernel_roofline(kernel_id, a, b, flops, name, run_pass, passes=2):
     """One kernel of a pass against the fp32 matrix peak, timed by the library's own HIP events around that kernel alone (hyb_profile_set) inside
     real passes -- the last matching launch of each pass."""
@@ -531,6 +543,7 @@ def fct_leg(dev, reps=5, frames=16, size=224):
         (_, (N_, L_, C_, heads_), _), _ = max(((k, v) for k, v in ept.totals.items() if k[0] == "hyb_fct_mha_bwd"), key=lambda kv: kv[1][1])
         kr = hooked_kernel_roofline(5, int(L_), int(heads_), 8.0 * N_ * L_ * L_ * C_, "flash_bwd4_dkv_kernel", train_pass)
         if kr:
+            kr["traffic"], kr["traffic_source"] = committed_traffic_f("fct", "flash_bwd4_dkv_kernel<1>")
             kr["what"] = (f"dK / dV kernel of FCT's attention backward, N={N_} L={L_} C={C_} heads={heads_}: recomputes S = QK^T, dP = dO V^T and forms "
                           "dV = P^T dO, dK = dS^T Q -- 8 L^2 C FLOP per image")
             res["kernel_roofline"] = kr
@@ -592,6 +605,8 @@ def enc32k_leg(dev, reps=5, frames=16):
         kr = hooked_kernel_roofline(4, int(Ci_), int(Kp), 2.0 * last * H_ * W_ * Ci_ * Kp,
                                     "gemm_nt_lds_kernel<%d, %d, true>" % ((128, 2) if Ci_ > 64 else (64, 3)) if Ci_ >= 64 else "gemm_nt_tall_kernel<4, true>", train_pass)
         if kr:
+            kr["traffic"], kr["traffic_source"] = committed_traffic_f("enc32k", kr["kernel"])
+            kr["algorithmic_bytes_per_launch"] = float(last * H_ * W_ * (Ci_ + Co8) * 4)
             kr["what"] = (f"input gradient of the {k_}x{k_} convolution {Ci_} -> {Co_} on {last} x {H_}x{W_} pixels (the last image chunk of {N_}) as an "
                           f"implicit GEMM: rows = input pixels, columns = {Ci_}, K = {Kp}")
             res["kernel_roofline"] = kr

@@ -32,8 +32,13 @@ template <int BN, int S> struct GtGeom {
     static constexpr size_t LDS_BYTES = (size_t)S * STAGE * 4;
 };
 
+// korder (IMPLICIT, Ci % 32 == 0): walk K channel-block-major -- for each 32-channel block its k*k taps in a row -- instead of tap-major.
+// Tap-major, the k*k shifted reads of a pixel's channels are Ci/32 steps (tens of us) apart and every one of them misses L2: the 3x3, 512-channel
+// layer of Encoder_32K fetched 1.25 GB for 134 MB of input (profiles/r04_pmc_fetch_write_enc32k.csv).  Channel-block-major they are consecutive
+// steps on a 25 KB working set per workgroup.  Row blocks are dealt to the XCDs in contiguous ranges for the same reason (neighbouring row
+// blocks share their halo rows in one L2).
 template <int BN, int S, bool IMPLICIT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs args, int tiles_n, int row_blocks, ConvGather cg) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs args, int tiles_n, int row_blocks, ConvGather cg, int korder) {
     using G = GtGeom<BN, S>;
     constexpr int BM = G::BM, NTW = G::NTW, A_I = G::A_I, B_I = G::B_I, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) float gt_smem[];
@@ -43,8 +48,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs args, int 
     float* C = (float*)grp.C;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, seq = bid >> 3;
-    const int tn = seq % tiles_n, rb = (seq / tiles_n) * 8 + xcd;           // the column tiles of one row block share an XCD (its L2 holds A)
-    if (rb >= row_blocks) return;
+    // the column tiles of one row block share an XCD (its L2 holds A); korder: XCD x owns row blocks [x * per, (x + 1) * per)
+    const int per_xcd = (row_blocks + 7) >> 3;
+    const int tn = seq % tiles_n, rb = korder ? xcd * per_xcd + seq / tiles_n : (seq / tiles_n) * 8 + xcd;
+    if (rb >= row_blocks || (korder && seq / tiles_n >= per_xcd)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
@@ -128,14 +135,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs args, int 
     };
 
     const int nk = (R + 31) >> 5;
+    const int kk = cg.k * cg.k, cstride = IMPLICIT ? (1 << cg.log2ci) : 0;
+    auto k_of = [&](int it) { return (IMPLICIT && korder) ? (it % kk) * cstride + (it / kk) * 32 : it * 32; };      // (beyond nk: >= R, all zeros)
 #pragma unroll
-    for (int s = 0; s < S - 1; ++s) issue(s, s * 32);                       // (steps beyond R: every lane out of range, zeros)
+    for (int s = 0; s < S - 1; ++s) issue(s, s < nk ? k_of(s) : R);         // (steps beyond R: every lane out of range, zeros)
     int buf = 0, nbuf = S - 1;
     for (int it = 0; it < nk; ++it) {
         gt_wait_vmcnt<(S - 2) * G::LW>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(nbuf, (it + S - 1) * 32);                                      // into the buffer every wave finished reading before this barrier
+        issue(nbuf, it + S - 1 < nk ? k_of(it + S - 1) : R);                 // into the buffer every wave finished reading before this barrier
         const float* st = gt_smem + buf * STAGE;
         Frag<float> a[4], b[NTW];
 #pragma unroll
@@ -200,7 +209,10 @@ void gt_go(const GemmArgs& a, const ConvGather& cg, long long blocks, int tiles_
         (void)hipFuncSetAttribute((const void*)gemm_nt_lds_kernel<BN, S, IMPLICIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         once = true;
     }
-    hipLaunchKernelGGL((gemm_nt_lds_kernel<BN, S, IMPLICIT>), dim3((unsigned)blocks), dim3(256), lds, st, a, tiles_n, row_blocks, cg);
+    static const int order_env = getenv("HYB_GEMM_LDS_ORDER") ? atoi(getenv("HYB_GEMM_LDS_ORDER")) : 1;      // (=0: A/B, tap-major K walk)
+    const int ci = IMPLICIT ? (1 << cg.log2ci) : 0;
+    const int korder = (IMPLICIT && order_env && ci % 32 == 0 && a.R == cg.k * cg.k * ci && cg.k > 1) ? 1 : 0;
+    hipLaunchKernelGGL((gemm_nt_lds_kernel<BN, S, IMPLICIT>), dim3((unsigned)blocks), dim3(256), lds, st, a, tiles_n, row_blocks, cg, korder);
 }
 
 template <bool IMPLICIT>

@@ -40,16 +40,22 @@ template <> struct WlVec<4> { typedef float __attribute__((ext_vector_type(4))) 
 template <int WN, int WK, int NKT, bool IMPL>
 __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                            float* __restrict__ part, float* __restrict__ cpart, long long P, int Nn, int K,
-                                                           int kgroups, int slice_rows, ConvGeo g) {
+                                                           int kgroups, int slice_rows, ConvGeo g, int tiles, int S_) {
     using G = WlGeom<WN, WK, NKT>;
     constexpr int BN = G::BN, BK = G::BK, A_I = G::A_I, B_I = G::B_I, STAGE = G::STAGE;
     extern __shared__ __attribute__((aligned(16))) float wl_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
-    const int kg = blockIdx.x % kgroups, ng = blockIdx.x / kgroups;
+    // flat grid, XCD-aware: workgroups v, v + 8, v + 16, .. (one XCD, one L2) take ALL (n, k) tiles of one pixel slice before the next -- the
+    // k tiles of a slice are the k*k shifted views of the same pixels (and every n tile re-reads x): dealt round-robin they were fetched once
+    // per XCD (3.5 x the algorithmic bytes on the 512 -> 128 layer, profiles/r04_pmc_fetch_write_enc32k.csv)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int slice = (seq / tiles) * 8 + xcd, tl = seq % tiles;
+    if (slice >= S_) return;
+    const int kg = tl % kgroups, ng = tl / kgroups;
     const int n0 = ng * BN, k0 = kg * BK;
-    const long long r_begin = (long long)blockIdx.y * slice_rows;
+    const long long r_begin = (long long)slice * slice_rows;
     const int rows = (int)((r_begin + slice_rows < P ? r_begin + slice_rows : P) - r_begin);
     const bool want_cs = cpart != nullptr && kg == 0;
 
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
     wl_wait_all();
 
     // accumulator (tile i, tile j)[r] of lane (m, kq) = dW[n0 + wn*64 + 4*(4*kq + r) + i][k0 + wk*NKT*16 + NKT*m + j]
-    float* out = part + (long long)blockIdx.y * Nn * K;
+    float* out = part + (long long)slice * Nn * K;
     const int kb = k0 + wk * (NKT * 16) + NKT * m;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < NKT; ++j)
                 if (kb + j < K) out[(long long)n * K + kb + j] = acc[i][j][r];
-            if (want_cs && m == 0 && wk == 0) cpart[(long long)blockIdx.y * Nn + n] = accs[i][r];
+            if (want_cs && m == 0 && wk == 0) cpart[(long long)slice * Nn + n] = accs[i][r];
         }
 }
 
@@ -207,9 +213,10 @@ void wl_go(const WlPlan& pl, const float* dy, int lddy, const float* x, int ldx,
         (void)hipFuncSetAttribute((const void*)wgrad_lds_kernel<WN, WK, NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         once = true;
     }
-    const dim3 grid(pl.ktiles * pl.ntiles, pl.S);
-    if (geo) hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK, NKT, true>), grid, dim3(256), lds, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, pl.ktiles, pl.rows, *geo);
-    else hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK, NKT, false>), grid, dim3(256), lds, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, pl.ktiles, pl.rows, ConvGeo{});
+    const int tiles = pl.ktiles * pl.ntiles;
+    const dim3 grid((unsigned)(hyb_cdiv(pl.S, 8) * 8 * tiles));
+    if (geo) hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK, NKT, true>), grid, dim3(256), lds, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, pl.ktiles, pl.rows, *geo, tiles, pl.S);
+    else hipLaunchKernelGGL((wgrad_lds_kernel<WN, WK, NKT, false>), grid, dim3(256), lds, st, dy, lddy, x, ldx, part, cpart, P, Nn, K, pl.ktiles, pl.rows, ConvGeo{}, tiles, pl.S);
 }
 inline void wl_launch(const WlPlan& pl, const float* dy, int lddy, const float* x, int ldx, float* part, float* cpart, long long P, int Nn, int K,
                       hipStream_t st, const ConvGeo* geo) {
