@@ -297,98 +297,6 @@ __global__ __launch_bounds__(256) void gemm_dw_multi_tr_kernel(DwArgs args) {
         }
 }
 
-// fp32-storage twin of gemm_dw_multi_tr_kernel ('fp32' / 'bf16x3' modes and the temporal part of 'mixed'): both operand tiles staged as
-// they lie in memory, all of up to 128 rows in one round, 16-byte loads and stores; a fragment's 8 K values are 8 consecutive ROWS of one
-// column, read as eight ds_read_b32 (16 lanes = 16 consecutive columns: conflict-free).  69.6 KB of LDS (dynamic).
-constexpr int DWF_ROWS = 128, DWF_STRIDE = 64 + 4;
-__device__ __forceinline__ void dwf_frag(Frag<float>& f, const float* tile, int m0, int c0, int lane) {
-    const float* a0 = tile + (m0 + 8 * (lane >> 4)) * DWF_STRIDE + c0 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = a0[j * DWF_STRIDE];
-}
-__global__ __launch_bounds__(256) void gemm_dw_multi_trf_kernel(DwArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float dwf_smem[];
-    float* const As = dwf_smem;
-    float* const Bs = dwf_smem + DWF_ROWS * DWF_STRIDE;
-    if ((int)blockIdx.x >= args.tiles) { dw_rider_block(args); return; }
-    int gi = 0;
-#pragma unroll
-    for (int i = 1; i < DW_MAX_GROUPS; ++i)
-        if (i < args.ngroups && (int)blockIdx.x >= args.g[i].tile_begin) gi = i;
-    const DwGroup grp = args.g[gi];
-    const int local = blockIdx.x - grp.tile_begin;
-    const int bx = local % grp.tiles_x, by = local / grp.tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = by * 64, n0 = bx * 64;                  // m0: rows of dW (columns of dy), n0: columns of dW (columns of x)
-    const int p = lane & 15, q = lane >> 4;
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float csum = 0.f;
-    const float* dy = (const float*)grp.dy;
-    const float* mk = (const float*)grp.mask;
-    const float* x = (const float*)grp.x;
-    const int seg = tid & 15, row_t = tid >> 4;            // thread: 4 columns seg*4.., rows row_t + 16 u
-    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < args.M; r0 += DWF_ROWS) {
-        if (r0 > 0) __syncthreads();
-        f32x4 va[8], vb[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = r0 + row_t + 16 * u;
-            const bool rok = r < args.M;
-            va[u] = z4; vb[u] = z4;
-            if (rok && m0 + seg * 4 < grp.N) {
-                va[u] = *reinterpret_cast<const f32x4*>(dy + (long long)r * grp.lddy + m0 + seg * 4);
-                if (mk) {
-                    const f32x4 vm = *reinterpret_cast<const f32x4*>(mk + (long long)r * grp.lddy + m0 + seg * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(vm[j] > 0.f)) va[u][j] = 0.f;
-                }
-            }
-            if (rok && n0 + seg * 4 < grp.K) vb[u] = *reinterpret_cast<const f32x4*>(x + (long long)r * grp.ldx + n0 + seg * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            *reinterpret_cast<f32x4*>(As + (row_t + 16 * u) * DWF_STRIDE + seg * 4) = va[u];
-            *reinterpret_cast<f32x4*>(Bs + (row_t + 16 * u) * DWF_STRIDE + seg * 4) = vb[u];
-        }
-        __syncthreads();
-        const int rows = args.M - r0 < DWF_ROWS ? args.M - r0 : DWF_ROWS;
-        if (grp.db && bx == 0 && tid < 64) {                // bias gradient: column sums of the (masked) dy tile, rows in ascending order
-            for (int r = 0; r < rows; ++r) csum += As[r * DWF_STRIDE + tid];
-        }
-        for (int k0 = 0; k0 < rows; k0 += 32) {             // rows beyond M are zero: a ragged last step contributes nothing
-            Frag<float> a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) dwf_frag(a[i], As, k0, wm * 32 + i * 16, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dwf_frag(b[j], Bs, k0, wn * 32 + j * 16, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mma32(a[i], b[j], acc[i][j]);
-        }
-    }
-    if (grp.db && bx == 0 && tid < 64 && m0 + tid < grp.N) grp.db[m0 + tid] = csum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int no = n0 + wn * 32 + j * 16 + p;
-            if (no >= grp.K) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mo = m0 + wm * 32 + i * 16 + 4 * q + r;
-                if (mo < grp.N) grp.dW[(long long)mo * grp.K + no] = acc[i][j][r];
-            }
-        }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_dw_multi_kernel(DwArgs args) {
     constexpr int BM = 64, WM = 32, MT = 2;
@@ -1124,16 +1032,9 @@ int hyb_linear_dw_multi(int dtype, int groups, const void* const* dy, const void
     for (int i = 0; i < groups; ++i)
         aligned = aligned && lddy[i] % 8 == 0 && ldx[i] % 8 == 0 && ((uintptr_t)dy[i] % 16 == 0) && ((uintptr_t)x[i] % 16 == 0) &&
                   (!mask || !mask[i] || (uintptr_t)mask[i] % 16 == 0);
-    bool aligned4 = true;                                  // fp32 rows: 16-byte = 4-element alignment
-    for (int i = 0; i < groups; ++i)
-        aligned4 = aligned4 && lddy[i] % 4 == 0 && ldx[i] % 4 == 0 && N[i] % 4 == 0 && K[i] % 4 == 0 && ((uintptr_t)dy[i] % 16 == 0) &&
-                   ((uintptr_t)x[i] % 16 == 0) && (!mask || !mask[i] || (uintptr_t)mask[i] % 16 == 0);
-    if (dtype == HYB_F32 && tr_env && aligned4) {
-        constexpr int lds = 2 * DWF_ROWS * DWF_STRIDE * (int)sizeof(float);
-        static HybAttrOnce once;
-        if (int e = hyb_set_lds_attr(once, (const void*)gemm_dw_multi_trf_kernel, lds)) return e;
-        hipLaunchKernelGGL(gemm_dw_multi_trf_kernel, dim3(blocks), dim3(256), lds, st, a);
-    } else if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    // (an fp32-storage twin of the untransposed-staging kernel -- eight ds_read_b32 per fragment instead of the transposing 16-bit read --
+    // was built and measured: 28.3 us against the 25.5 us of the generic kernel below, profiles/r04_ab_mixed_f32_twins.txt; not kept)
+    if (dtype == HYB_F32) hipLaunchKernelGGL(gemm_dw_multi_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16 && tr_env && aligned) hipLaunchKernelGGL(gemm_dw_multi_tr_kernel, dim3(blocks), dim3(256), 0, st, a);
     else if (dtype == HYB_BF16) hipLaunchKernelGGL(gemm_dw_multi_kernel<bf16>, dim3(blocks), dim3(256), 0, st, a);
     else return HYB_E_ARG;
